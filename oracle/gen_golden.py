@@ -1,0 +1,316 @@
+"""Generate golden vectors from the REFERENCE's own code (build container only).
+
+TEST INFRASTRUCTURE.  Runs only where /root/reference exists; imports the
+reference's modules at run time and writes DATA (inputs + expected outputs) to
+tests/golden/.  No reference source is copied.
+
+What runs unmodified from the reference:
+  * evaluation.inference_kangaroo.kangaroo_forward  (the state machine)
+  * kangaroo.adapter.AdapterModel                    (the adapter)
+  * kangaroo.adapter.LlamaAttention / LlamaMLP / LlamaRMSNorm (layer arithmetic)
+What this script composes around them (the reference's own
+EarlyExitLlamaForCausalLM needs transformers==4.33.3 internals that the
+installed transformers no longer has): a duck-typed base model that stacks the
+reference's layer classes into the two-half Llama decoder layer and follows
+kangaroo/earlyexit.py:14-71 for the split forward, using the reference
+AdapterModel._prepare_decoder_attention_mask for masks.  `fastchat`/`shortuuid`
+(absent) are stubbed in sys.modules so that the module imports.
+
+Usage:  python oracle/gen_golden.py            # writes tests/golden/*.npz
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+import json
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("KANGAROO_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+
+
+def _import_reference():
+    for name in ["fastchat", "fastchat.utils", "fastchat.llm_judge", "fastchat.llm_judge.common",
+                 "fastchat.model", "shortuuid", "ray"]:
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            sys.modules[name] = m
+    sys.modules["fastchat.utils"].str_to_torch_dtype = lambda s: getattr(torch, s)
+    sys.modules["fastchat.llm_judge.common"].load_questions = lambda *a, **k: []
+    sys.modules["fastchat.model"].load_model = None
+    sys.modules["fastchat.model"].get_conversation_template = None
+    sys.path.insert(0, REF)
+    import kangaroo.adapter as ref_adapter
+    try:
+        from evaluation.inference_kangaroo import kangaroo_forward as ref_forward
+    except Exception as exc:  # pragma: no cover - reported to the caller
+        raise RuntimeError(f"could not import the reference loop: {exc!r}")
+    return ref_adapter, ref_forward
+
+
+class _Out:
+    pass
+
+
+class ComposedBase(torch.nn.Module):
+    """Base model built from the reference's layer classes (see module docstring)."""
+
+    def __init__(self, ref_adapter, cfg, early_exit_layer):
+        super().__init__()
+        A = ref_adapter
+        self.cfg = cfg
+        self.early_exit_layer = early_exit_layer
+        self.past_key_values = None
+        self.embed = torch.nn.Embedding(cfg.vocab_size, cfg.hidden_size)
+        self.attn = torch.nn.ModuleList([A.LlamaAttention(cfg) for _ in range(cfg.num_hidden_layers)])
+        self.mlp = torch.nn.ModuleList([A.LlamaMLP(cfg) for _ in range(cfg.num_hidden_layers)])
+        self.n1 = torch.nn.ModuleList([A.LlamaRMSNorm(cfg.hidden_size, cfg.rms_norm_eps) for _ in range(cfg.num_hidden_layers)])
+        self.n2 = torch.nn.ModuleList([A.LlamaRMSNorm(cfg.hidden_size, cfg.rms_norm_eps) for _ in range(cfg.num_hidden_layers)])
+        self.norm = A.LlamaRMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
+        self.lm_head = torch.nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False)
+        self._masker = A.AdapterModel._prepare_decoder_attention_mask
+
+    def load(self, sd):
+        with torch.no_grad():
+            self.embed.weight.copy_(sd["model.embed_tokens.weight"].float())
+            for i in range(self.cfg.num_hidden_layers):
+                p = f"model.layers.{i}."
+                for n in "qkvo":
+                    getattr(self.attn[i], n + "_proj").weight.copy_(sd[p + f"self_attn.{n}_proj.weight"].float())
+                for n in ("gate", "up", "down"):
+                    getattr(self.mlp[i], n + "_proj").weight.copy_(sd[p + f"mlp.{n}_proj.weight"].float())
+                self.n1[i].weight.copy_(sd[p + "input_layernorm.weight"].float())
+                self.n2[i].weight.copy_(sd[p + "post_attention_layernorm.weight"].float())
+            self.norm.weight.copy_(sd["model.norm.weight"].float())
+            self.lm_head.weight.copy_(sd["lm_head.weight"].float())
+
+    def _mask(self, q_len, past, like):
+        am = torch.ones((1, q_len + past), dtype=torch.bool)
+        return self._masker(None, am, (1, q_len), like, past)
+
+    def _layer(self, i, h, mask, pos, past):
+        a, _, present = self.attn[i](self.n1[i](h), attention_mask=mask, position_ids=pos,
+                                     past_key_value=past, use_cache=True)
+        h = h + a
+        h = h + self.mlp[i](self.n2[i](h))
+        return h, present
+
+    @torch.no_grad()
+    def forward(self, input_ids, position_ids=None, output_hidden_states=True):
+        h = self.embed(input_ids)
+        T = input_ids.shape[1]
+        mask = self._mask(T, 0, h)
+        hs, kvs = [], []
+        for i in range(self.cfg.num_hidden_layers):
+            hs.append(h)
+            h, present = self._layer(i, h, mask, position_ids, None)
+            kvs.append(present)
+        hn = self.norm(h)
+        hs.append(hn)
+        o = _Out()
+        o.logits = self.lm_head(hn)
+        o.hidden_states = tuple(hs)
+        o.past_key_values = tuple(kvs)
+        return o
+
+    @torch.no_grad()
+    def forward_draft_or_large_model(self, in_tokens_small=None, in_features_large=None, position_ids=None):
+        assert self.past_key_values is not None
+        if in_tokens_small is not None and in_features_large is not None:
+            raise ValueError("both")
+        small = in_tokens_small is not None
+        if not small and in_features_large is None:
+            raise ValueError("neither")
+        q_len = in_tokens_small.shape[1] if small else in_features_large.shape[1]
+        focus = 0 if small else self.early_exit_layer
+        past = self.past_key_values[focus][0].shape[2]
+        h = self.embed(in_tokens_small) if small else in_features_large
+        mask = self._mask(q_len, past, h)
+        rng = range(0, self.early_exit_layer) if small else range(self.early_exit_layer, self.cfg.num_hidden_layers)
+        for i in rng:
+            h, present = self._layer(i, h, mask, position_ids, self.past_key_values[i])
+            self.past_key_values[i] = present
+        if not small:
+            return h, self.norm(h)
+        return h
+
+
+class RefKangaroo:
+    def __init__(self, base, adapter, head):
+        self.base_model, self.adapter_model, self.head_model = base, adapter, head
+
+
+class _Tok:
+    def __init__(self, eos):
+        self.eos_token_id = eos
+
+
+class _Inputs:
+    def __init__(self, ids):
+        self.input_ids = ids
+
+
+def build_reference_model(ref_adapter, shape, base_sd, adapter_sd, exit_layer):
+    from transformers.models.llama import LlamaConfig
+    cfg = LlamaConfig(hidden_size=shape.hidden_size, intermediate_size=shape.intermediate_size,
+                      num_hidden_layers=shape.num_hidden_layers, num_attention_heads=shape.num_attention_heads,
+                      num_key_value_heads=shape.num_key_value_heads, vocab_size=shape.vocab_size,
+                      rms_norm_eps=shape.rms_norm_eps, max_position_embeddings=shape.max_position_embeddings,
+                      hidden_act="silu", pad_token_id=0)
+    base = ComposedBase(ref_adapter, cfg, exit_layer).eval()
+    base.load(base_sd)
+    acfg = LlamaConfig(**{**cfg.to_dict(), "num_hidden_layers": 1})
+    adapter = ref_adapter.AdapterModel(acfg).eval()
+    missing = adapter.load_state_dict({k: v.float() for k, v in adapter_sd.items()}, strict=False)
+    assert not [k for k in missing.missing_keys if "rotary" not in k], missing
+    head = torch.nn.Linear(shape.hidden_size, shape.vocab_size, bias=False)
+    head.weight.data = base_sd["lm_head.weight"].float()
+    return RefKangaroo(base, adapter, head.eval())
+
+
+def run_reference(ref_forward, model, ids, eos, max_new_tokens, exit_layer, steps, threshold):
+    """Run the unmodified reference loop, recording per-round draft lengths, per-step
+    confidences and logits through call-counting wrappers (no reference edits)."""
+    rec = {"adapter_calls": 0, "draft_lengths": [], "head_rows": [], "verify_logits": [], "draft_logits": []}
+    ad_orig = model.adapter_model.forward_early_stop
+    head_orig = model.head_model.forward
+    base_orig = model.base_model.forward_draft_or_large_model
+
+    def ad_wrap(*a, **k):
+        rec["adapter_calls"] += 1
+        return ad_orig(*a, **k)
+
+    def base_wrap(*a, **k):
+        if k.get("in_features_large") is not None:
+            rec["draft_lengths"].append(rec["adapter_calls"])
+            rec["adapter_calls"] = 0
+            rec["verify_next"] = True
+        return base_orig(*a, **k)
+
+    def head_wrap(x):
+        y = head_orig(x)
+        if rec.get("verify_next"):
+            rec["verify_logits"].append(y[0].clone())
+            rec["verify_next"] = False
+        else:
+            rec["draft_logits"].append(y[0].clone())
+        return y
+
+    model.adapter_model.forward_early_stop = ad_wrap
+    model.base_model.forward_draft_or_large_model = base_wrap
+    model.head_model.forward = head_wrap
+    try:
+        out = ref_forward(_Inputs(ids), model, _Tok(eos), max_new_tokens, EARLY_STOP_LAYER=exit_layer,
+                          SPECULATIVE_DECODING_STEPS=steps, threshold=threshold)
+    finally:
+        model.adapter_model.forward_early_stop = ad_orig
+        model.base_model.forward_draft_or_large_model = base_orig
+        model.head_model.forward = head_orig
+    # the first adapter call is the prefill (inference_kangaroo.py:38): it is counted
+    # into the first round by the wrapper, remove it
+    rec["draft_lengths"][0] -= 1 if rec["draft_lengths"] else 0
+    return out, rec
+
+
+CASES = [
+    # name, shape, exit_layer, steps, threshold, recipe kwargs, seed, prompt lens, max_new
+    ("tiny_random", "tiny", 2, 6, 0.6, dict(), 1, [5, 12], 40),
+    ("tiny_agree_h12_d0", "tiny", 2, 6, 0.6, dict(deep_scale=0.0, head_scale=12.0, adapter_o_zero=True, adapter_norm_from_base=True), 2, [7, 16, 3], 64),
+    ("tiny_agree_h8_d03", "tiny", 2, 6, 0.6, dict(deep_scale=0.3, head_scale=8.0, adapter_o_zero=True, adapter_norm_from_base=True), 3, [9, 21], 64),
+    ("tiny_agree_h10_d05_s3", "tiny", 1, 3, 0.4, dict(deep_scale=0.5, head_scale=10.0, adapter_o_zero=True, adapter_norm_from_base=True), 4, [11, 4], 48),
+    ("tinymha_agree_h10_d02_L3", "tiny-mha", 3, 6, 0.6, dict(deep_scale=0.2, head_scale=10.0, adapter_o_zero=True, adapter_norm_from_base=True), 5, [8, 30], 64),
+    ("tiny_thr0", "tiny", 2, 6, 0.0, dict(deep_scale=0.3, head_scale=8.0, adapter_o_zero=True, adapter_norm_from_base=True), 6, [10], 48),
+    ("tiny_thr2", "tiny", 2, 6, 2.0, dict(deep_scale=0.3, head_scale=8.0, adapter_o_zero=True, adapter_norm_from_base=True), 7, [10], 48),
+]
+
+
+def main():
+    from kangaroo_amd.config import get_shape
+    from kangaroo_amd.weights import synth_state_dicts, Recipe
+    ref_adapter, ref_forward = _import_reference()
+    outdir = os.path.join(REPO, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    summary = {}
+    for name, shape_name, L, steps, thr, rk, seed, plens, max_new in CASES:
+        shape = get_shape(shape_name)
+        base_sd, adapter_sd = synth_state_dicts(shape, L, seed=seed, dtype=torch.float16, recipe=Recipe(**rk))
+        model = build_reference_model(ref_adapter, shape, base_sd, adapter_sd, L)
+        blob = {"meta": json.dumps(dict(shape=shape_name, exit_layer=L, steps=steps, threshold=thr, recipe=rk,
+                                        seed=seed, max_new_tokens=max_new, eos=2, n_prompts=len(plens)))}
+        for k, v in base_sd.items():
+            blob["base/" + k] = v.numpy()
+        for k, v in adapter_sd.items():
+            blob["adapter/" + k] = v.numpy()
+        accs = []
+        for pi, plen in enumerate(plens):
+            g = torch.Generator().manual_seed(1000 * seed + pi)
+            ids = torch.randint(3, shape.vocab_size, (1, plen), generator=g)
+            (out_ids, new_token, idx, accept), rec = run_reference(ref_forward, model, ids, 2, max_new, L, steps, thr)
+            # losslessness against a plain greedy decode through the same reference layers
+            blob[f"p{pi}/input_ids"] = ids.numpy()
+            blob[f"p{pi}/output_ids"] = np.asarray(out_ids[0], dtype=np.int64)
+            blob[f"p{pi}/new_token"] = np.asarray(new_token)
+            blob[f"p{pi}/idx"] = np.asarray(idx)
+            blob[f"p{pi}/accept_length_list"] = np.asarray(accept, dtype=np.int64)
+            blob[f"p{pi}/draft_lengths"] = np.asarray(rec["draft_lengths"], dtype=np.int64)
+            dl = rec["draft_logits"]
+            blob[f"p{pi}/draft_logits"] = torch.stack([x[-1] for x in dl]).numpy() if dl else np.zeros((0, shape.vocab_size), np.float32)
+            blob[f"p{pi}/p_max"] = np.asarray([float(x[-1].float().softmax(-1).max()) for x in dl], dtype=np.float64)
+            vl = rec["verify_logits"]
+            blob[f"p{pi}/verify_logits"] = torch.cat(vl, 0).numpy() if vl else np.zeros((0, shape.vocab_size), np.float32)
+            accs.append(accept)
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), **blob)
+        summary[name] = accs
+        print(name, accs)
+    # layer-level vectors straight from the reference classes
+    layer_vectors(ref_adapter, outdir)
+    with open(os.path.join(outdir, "SUMMARY.json"), "w") as f:
+        json.dump(summary, f)
+
+
+def layer_vectors(A, outdir):
+    """RMSNorm / RoPE / attention / adapter-layer vectors from kangaroo.adapter classes."""
+    from transformers.models.llama import LlamaConfig
+    torch.manual_seed(123)
+    cfg = LlamaConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=4,
+                      num_key_value_heads=2, vocab_size=97, rms_norm_eps=1e-6, max_position_embeddings=2048, pad_token_id=0)
+    blob = {}
+    x = torch.randn(1, 5, 64)
+    n = A.LlamaRMSNorm(64, 1e-6)
+    n.weight.data = 1 + 0.1 * torch.randn(64)
+    blob["rms/x"], blob["rms/w"], blob["rms/y"] = x.numpy(), n.weight.data.numpy(), n(x).detach().numpy()
+    rot = A.LlamaRotaryEmbedding(16, 2048)
+    cos, sin = rot(x, seq_len=40)
+    q = torch.randn(1, 4, 5, 16)
+    k = torch.randn(1, 2, 5, 16)
+    pos = torch.tensor([[3, 4, 9, 17, 39]])
+    qe, ke = A.apply_rotary_pos_emb(q, k, cos, sin, pos)
+    blob.update({"rope/q": q.numpy(), "rope/k": k.numpy(), "rope/pos": pos.numpy(), "rope/qe": qe.numpy(), "rope/ke": ke.numpy(),
+                 "rope/cos": cos[0, 0].numpy(), "rope/sin": sin[0, 0].numpy()})
+    mlp = A.LlamaMLP(cfg)
+    blob.update({"mlp/x": x.numpy(), "mlp/wg": mlp.gate_proj.weight.detach().numpy(), "mlp/wu": mlp.up_proj.weight.detach().numpy(),
+                 "mlp/wd": mlp.down_proj.weight.detach().numpy(), "mlp/y": mlp(x).detach().numpy()})
+    ad = A.AdapterModel(cfg).eval()
+    with torch.no_grad():
+        for p in ad.parameters():
+            p.copy_(torch.randn_like(p) * (0.125 if p.ndim == 2 else 0.1) + (0 if p.ndim == 2 else 1))
+        x0 = torch.randn(1, 6, 64)
+        y0, kv = ad.forward_early_stop(inputs_embeds=x0, position_ids=torch.arange(6).view(1, -1), use_cache=True)
+        x1 = torch.randn(1, 1, 64)
+        y1, kv1 = ad.forward_early_stop(inputs_embeds=x1, position_ids=torch.tensor([[6]]), past_key_values=kv, use_cache=True)
+        x2 = torch.randn(1, 2, 64)
+        y2, kv2 = ad.forward_early_stop(inputs_embeds=x2, position_ids=torch.tensor([[7, 8]]), past_key_values=kv1, use_cache=True)
+    for kname, v in ad.state_dict().items():
+        blob["adapter/" + kname] = v.numpy()
+    blob.update({"ad/x0": x0.numpy(), "ad/y0": y0.numpy(), "ad/x1": x1.numpy(), "ad/y1": y1.numpy(), "ad/x2": x2.numpy(),
+                 "ad/y2": y2.numpy(), "ad/k2": kv2[0][0].numpy(), "ad/v2": kv2[0][1].numpy()})
+    np.savez_compressed(os.path.join(outdir, "layers.npz"), **blob)
+    print("layers.npz written")
+
+
+if __name__ == "__main__":
+    main()
