@@ -1,0 +1,168 @@
+/* C ABI of libkangaroo_hip.so: the MI355X (gfx950) decode path of Kangaroo
+ * (double-early-exit self-speculative greedy decoding, batch size 1).
+ *
+ * The reference is pure Python on eager PyTorch and has no FFI of its own; each entry
+ * point below names the reference code it stands in for.  All pointers marked "device"
+ * are HIP device pointers owned by the caller (PyTorch allocates them); the library
+ * never frees caller memory.  Every function returns 0 on success and a negative code
+ * on failure (-1 bad argument, -2 HIP error, -3 does not fit on chip);
+ * kg_last_error() gives the text.  Nothing throws.  `stream` is a hipStream_t passed
+ * as void* (torch.cuda.current_stream().cuda_stream).
+ *
+ * Weight layout ("packed"): a Linear weight W[N][K] (row-major, as HF stores it) is
+ * padded to ceil16(N) rows and stored as 1 KiB tiles of 16 rows x 32 k; tile (rg, kt)
+ * sits at element offset (rg * K/32 + kt) * 512, and inside a tile element (g, r, j) at
+ * g*128 + r*8 + j is W[16*rg + r][32*kt + 8*g + j].  kangaroo_amd/packing.py produces it.
+ * Row order before packing:
+ *   wqkv   rows = [q heads | k heads | v heads]; inside every head the rows are
+ *          interleaved (j, j + hd/2) -> (2j, 2j+1) so a RoPE pair is adjacent
+ *   wgu    rows (2i, 2i+1) = (gate_proj row i, up_proj row i)
+ *   wo, wdown, lm_head   natural order
+ */
+#ifndef KANGAROO_HIP_H
+#define KANGAROO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KG_DTYPE_F16 0
+#define KG_DTYPE_BF16 1
+#define KG_MAX_ROWS 16
+
+typedef struct kg_session kg_session;
+
+typedef struct {
+    int dtype;                 /* KG_DTYPE_* : storage and MAC input type (fp32 accumulate) */
+    int hidden_size, num_layers, num_heads, num_kv_heads, head_dim;
+    int intermediate_size, vocab_size;
+    float rms_eps;
+    int max_positions;         /* rows of the RoPE tables */
+    int exit_layer;            /* EARLY_STOP_LAYER: layers [0, exit) draft, [exit, N) verify */
+} kg_shape;
+
+typedef struct {
+    const void* wqkv;          /* packed [(H + 2 Hkv) hd, d] */
+    const void* wo;            /* packed [d, H hd] */
+    const void* wgu;           /* packed [2 F, d]; NULL for the adapter layer */
+    const void* wdown;         /* packed [d, F];   NULL for the adapter layer */
+    const void* norm1;         /* [d] input_layernorm */
+    const void* norm2;         /* [d] post_attention_layernorm; NULL for the adapter */
+} kg_layer_weights;
+
+typedef struct {
+    const void* embed;         /* [V, d] row-major */
+    const void* final_norm;    /* [d] model.norm */
+    const void* lm_head;       /* packed [V, d] (the reference keeps a separate copy as head_model) */
+    const kg_layer_weights* layers;   /* host array of num_layers entries (copied) */
+    kg_layer_weights adapter;  /* the adapter's single attention-only layer */
+    const void* adapter_norm;  /* [d] adapter final norm */
+    const float* rope_cos;     /* [max_positions, hd/2] fp32 */
+    const float* rope_sin;
+} kg_weights;
+
+typedef struct {
+    void* k_cache;             /* [num_layers][Hkv][t_max][hd] */
+    void* v_cache;
+    void* ak_cache;            /* adapter: [Hkv][t_max][hd] */
+    void* av_cache;
+    void* workspace;           /* >= kg_workspace_bytes(), zero-filled by the caller */
+    size_t workspace_bytes;
+    int t_max;                 /* cache rows = max_length of the loop (2048 in the reference) */
+} kg_buffers;
+
+typedef struct {
+    int n_tokens;              /* len(output_ids) = start_index + 1 */
+    int new_tokens;            /* start_index - context_length + 1 */
+    int rounds;                /* verify rounds (= idx of the reference's return) */
+    int drafted_total;         /* adapter steps over all rounds */
+    int stopped_on_eos;
+    float prefill_ms;          /* device time of the prefill */
+    float decode_ms;           /* device time of the draft/verify loop */
+} kg_gen_result;
+
+int kg_version(void);
+const char* kg_last_error(void);
+
+/* ---- kernel-level entry points (unit parity tests call these) -------------------- */
+
+/* y = x W^T for n_rows <= 16 rows with the fused prologue/epilogue of the decode path.
+ * Stands in for torch.nn.functional.linear as the reference's layers call it
+ * (kangaroo/adapter.py:170-172,222,242; kangaroo/kangaroo_model.py:34).
+ *   prologue 0: x used as is; 1: x = RMSNorm(x; norm_w, eps) (adapter.py:254-259)
+ *   epilogue 0: out = y; 1: out = resid + y (adapter.py:304); 3: out = silu(y_gate) * y_up
+ *            (adapter.py:242, rows interleaved as wgu)
+ * n_rows == 1 runs the wave-reduced GEMV, n_rows > 1 the MFMA kernel. */
+int kg_linear(int dtype, const void* w_packed, int N, int K, const void* x, int n_rows,
+              int prologue, const void* norm_w, float eps,
+              int epilogue, const void* resid, void* out, int out_stride,
+              void* scratch /* device, >= 256 B */, int nblocks, int nwaves, void* stream);
+
+/* Fused RMSNorm + QKV projection + RoPE + in-place KV append for n_rows rows at
+ * positions pos0.. (adapter.py:170-189 with the cache growing by torch.cat there). */
+int kg_qkv_rope_append(int dtype, const void* wqkv_packed, int d, int n_heads, int n_kv_heads, int head_dim,
+                       const void* x, int n_rows, int pos0, const void* norm_w, float eps,
+                       const float* rope_cos, const float* rope_sin,
+                       void* q_out, void* k_cache, void* v_cache, int t_max,
+                       void* scratch, int nblocks, int nwaves, void* stream);
+
+/* Causal attention of n_rows query rows at positions pos0.. over the cache rows
+ * [0, pos0 + n_rows) (adapter.py:191-221; the mask of :38-67 is the causal bound). */
+int kg_attention(int dtype, const void* q, int n_rows, int pos0, const void* k_cache, const void* v_cache,
+                 int n_heads, int n_kv_heads, int head_dim, int t_max, int nsplit,
+                 void* out, void* scratch /* device, kg_attention_scratch_bytes() */, void* stream);
+size_t kg_attention_scratch_bytes(int n_heads, int head_dim, int nsplit);
+
+/* lm_head + per-row argmax + softmax max (inference_kangaroo.py:79-83, 91-92).
+ * logits_out may be NULL.  prologue as kg_linear. */
+int kg_head(int dtype, const void* w_packed, int vocab, int d, const void* x, int n_rows,
+            int prologue, const void* norm_w, float eps,
+            void* logits_out, int* argmax_out, float* pmax_out,
+            void* scratch /* device, kg_head_scratch_bytes() */, int nblocks, int nwaves, void* stream);
+size_t kg_head_scratch_bytes(int vocab);
+
+/* ---- model-level entry points ---------------------------------------------------- */
+
+size_t kg_workspace_bytes(const kg_shape* shape, int t_max);
+int kg_session_create(const kg_shape* shape, const kg_weights* weights, const kg_buffers* buffers, kg_session** out);
+int kg_session_destroy(kg_session* s);
+/* tuning knobs: key in {"vec_blocks_per_cu","mfma_blocks_per_cu","vec_waves","mfma_waves","attn_nsplit"} */
+int kg_session_set(kg_session* s, const char* key, int value);
+
+/* Device address of a named region of the workspace ("tokens": int32[t_max], "state":
+ * int32 loop state, "hs_early": the exit layer's input rows kept by the last prefill
+ * [t_max, d], "head_tok" int32[16], "head_pmax" float[16]); NULL for an unknown name. */
+void* kg_session_ptr(kg_session* s, const char* name);
+
+/* Copy token ids into the session's device token buffer at [pos0, pos0 + n). */
+int kg_set_tokens(kg_session* s, const int32_t* tokens_host, int pos0, int n, void* stream);
+
+/* Layers [layer_begin, layer_end) of the base model on n_rows <= 16 rows at positions
+ * pos0.., appending their K/V at cache slots pos0...  x_in == NULL embeds
+ * tokens[pos0 + i] first (EarlyExitLlamaForCausalLM.forward_draft_or_large_model,
+ * kangaroo/earlyexit.py:41-66, and the prefill call inference_kangaroo.py:30). */
+int kg_forward_layers(kg_session* s, int layer_begin, int layer_end, const void* x_in, int pos0, int n_rows,
+                      void* h_out, void* stream);
+/* model.norm (earlyexit.py:69) */
+int kg_final_norm(kg_session* s, const void* x, int n_rows, void* out, void* stream);
+/* AdapterModel.forward_early_stop (kangaroo/adapter.py:378-460) on n_rows rows at pos0.. */
+int kg_adapter_forward(kg_session* s, const void* x_in, int pos0, int n_rows, void* h_out, void* stream);
+/* head_model (kangaroo/kangaroo_model.py:34-44) on already-normalised rows */
+int kg_head_logits(kg_session* s, const void* x, int n_rows, void* logits_out, int* argmax_out, float* pmax_out, void* stream);
+
+/* The whole kangaroo_forward (evaluation/inference_kangaroo.py:15-129): prefill, then
+ * draft / verify rounds replayed from a captured graph; the early-exit test, accept /
+ * reject and cache rollback run on the device.  mode 0 = Kangaroo, 1 = plain greedy
+ * decoding on the same kernels (the comparator, inference_baseline.py:14-25).
+ * out_tokens_host receives n_tokens ids; accept_log_host (may be NULL) receives per
+ * round (accept_length, drafted) pairs.  Synchronises `stream` before returning. */
+int kg_generate(kg_session* s, int mode, const int32_t* prompt_host, int context_length, int max_new_tokens,
+                int max_length, int steps, double threshold, int eos_token_id,
+                int32_t* out_tokens_host, int32_t* accept_log_host, int accept_log_capacity,
+                kg_gen_result* result, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

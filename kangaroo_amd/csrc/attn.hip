@@ -1,0 +1,218 @@
+// Decode attention over the in-place KV cache (gfx950): q rows 1..16 against T cached keys.
+//
+// One block = one (query head, T-split, block of <= MR query rows).  K and V rows are
+// streamed straight into VGPRs: a wave-level load covers 64/LPR consecutive cache rows
+// (1 KiB, fully coalesced), LPR = hd/8 lanes per row.  Scores use v_dot2 + an
+// LPR-lane shuffle reduction, softmax is online (running max / sum per row) in fp32,
+// P.V accumulates per lane for its 8 head dims.  Waves of a block, then T-splits, are
+// merged with the usual (max, sum, acc) rule; the causal bound of row m is its own
+// cache slot pos[m] (keys at slots > pos[m] are excluded), which replaces the
+// reference's additive mask tensors (kangaroo/adapter.py:38-67, 327-348).
+#include "kg_common.h"
+#include "kg_kernels.h"
+
+#define ATT_U 4         // K and V loads in flight per lane per batch
+#define ATT_NW 4        // waves per block
+
+template <int DT, int LPR, int MR>
+__global__ void __launch_bounds__(ATT_NW * 64) kg_attn_kernel(const KgAttnArgs a) {
+    typedef KgT<DT> T;
+    const KgDyn* dyn = a.dyn;
+    if (dyn->active == 0) return;
+    const int M = dyn->n_rows;
+    const int m0 = blockIdx.z * MR;
+    if (m0 >= M) return;
+    const int mr = min(MR, M - m0);
+    const int len = dyn->pos[M - 1] + 1;
+    const int h = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+    const int hd = LPR * 8;
+    const int kvh = h / (a.H / a.Hkv);
+    constexpr int RPI = 64 / LPR;                  // cache rows per wave-level load
+    constexpr int BR = ATT_U * RPI;                // rows per batch
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane % LPR, rsub = lane / LPR;
+
+    int chunk = (len + nsplit - 1) / nsplit;
+    chunk = (chunk + BR - 1) / BR * BR;
+    const int tbeg = split * chunk, tend = min(len, tbeg + chunk);
+
+    // query fragments (this lane's 8 dims of every row) and causal limits
+    kg_u4 qf[MR];
+    int lim[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const int mm = (m < mr) ? (m0 + m) : m0;
+        qf[m] = *((const kg_u4*)((const unsigned short*)a.q + (size_t)mm * a.H * hd + (size_t)h * hd) + c);
+        lim[m] = (m < mr) ? dyn->pos[mm] : -1;
+    }
+    float mrun[MR], lsum[MR], acc[MR][8];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        mrun[m] = -INFINITY; lsum[m] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[m][j] = 0.f;
+    }
+    const float inv_scale = sqrtf((float)hd);
+    const unsigned short* kbase = (const unsigned short*)a.k_cache + (size_t)kvh * a.t_max * hd;
+    const unsigned short* vbase = (const unsigned short*)a.v_cache + (size_t)kvh * a.t_max * hd;
+
+    for (int tb = tbeg + wave * BR; tb < tend; tb += ATT_NW * BR) {
+        kg_u4 kv[ATT_U], vv[ATT_U];
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) {
+            const int t = tb + u * RPI + rsub;
+            const bool ok = t < tend;
+            const size_t off = (size_t)(ok ? t : tbeg) * hd;
+            kv[u] = *((const kg_u4*)(kbase + off) + c);
+            vv[u] = *((const kg_u4*)(vbase + off) + c);
+            if (!ok) { vv[u].x = 0; vv[u].y = 0; vv[u].z = 0; vv[u].w = 0; }
+        }
+        float sc[ATT_U][MR];
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) {
+            const int t = tb + u * RPI + rsub;
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                float d = 0.f;
+                d = T::dot2(kv[u].x, qf[m].x, d);
+                d = T::dot2(kv[u].y, qf[m].y, d);
+                d = T::dot2(kv[u].z, qf[m].z, d);
+                d = T::dot2(kv[u].w, qf[m].w, d);
+#pragma unroll
+                for (int o = 1; o < LPR; o <<= 1) d += __shfl_xor(d, o, 64);
+                // reference op boundaries: q.k^T stored, then divided by sqrt(hd) and stored
+                d = kg_round<DT>(kg_round<DT>(d) / inv_scale);
+                sc[u][m] = (t < tend && t <= lim[m]) ? d : -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m < mr) {
+                float bm = sc[0][m];
+#pragma unroll
+                for (int u = 1; u < ATT_U; ++u) bm = fmaxf(bm, sc[u][m]);
+#pragma unroll
+                for (int o = LPR; o < 64; o <<= 1) bm = fmaxf(bm, __shfl_xor(bm, o, 64));
+                const float mnew = fmaxf(mrun[m], bm);
+                if (mnew > -INFINITY) {
+                    const float scale = (mrun[m] == -INFINITY) ? 0.f : expf(mrun[m] - mnew);
+                    lsum[m] *= scale;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[m][j] *= scale;
+#pragma unroll
+                    for (int u = 0; u < ATT_U; ++u) {
+                        const float p = (sc[u][m] == -INFINITY) ? 0.f : expf(sc[u][m] - mnew);
+                        lsum[m] += p;
+                        kg_us8 vh = __builtin_bit_cast(kg_us8, vv[u]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[m][j] += p * T::to_f(vh[j]);
+                    }
+                    mrun[m] = mnew;
+                }
+            }
+        }
+    }
+    // ---- merge the row groups of this wave (lanes that share c) ----
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+            lsum[m] += __shfl_xor(lsum[m], o, 64);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[m][j] += __shfl_xor(acc[m][j], o, 64);
+        }
+    }
+    // ---- merge waves through LDS ----
+    __shared__ float s_o[ATT_NW][MR][LPR * 8];
+    __shared__ float s_ml[ATT_NW][MR][2];
+    if (rsub == 0) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s_o[wave][m][c * 8 + j] = acc[m][j];
+            if (c == 0) { s_ml[wave][m][0] = mrun[m]; s_ml[wave][m][1] = lsum[m]; }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < mr * hd; i += blockDim.x) {
+        const int m = i / hd, dmi = i - m * hd;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < ATT_NW; ++w) mx = fmaxf(mx, s_ml[w][m][0]);
+        float o = 0.f, l = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATT_NW; ++w) {
+            const float wm = s_ml[w][m][0];
+            const float f = (wm == -INFINITY) ? 0.f : expf(wm - mx);
+            o += f * s_o[w][m][dmi];
+            l += f * s_ml[w][m][1];
+        }
+        const int mm = m0 + m;
+        if (nsplit == 1) {
+            ((unsigned short*)a.out)[(size_t)mm * a.H * hd + (size_t)h * hd + dmi] = T::from_f(o / l);
+        } else {
+            a.part_o[(((size_t)split * a.max_rows + mm) * a.H + h) * hd + dmi] = o;
+            if (dmi == 0) {
+                float* ml = a.part_ml + (((size_t)split * a.max_rows + mm) * a.H + h) * 2;
+                ml[0] = mx; ml[1] = l;
+            }
+        }
+    }
+}
+
+// out[m][h][:] = sum_s w_s o_s / sum_s w_s l_s,  w_s = exp(m_s - max_s m_s)
+template <int DT>
+__global__ void kg_attn_combine_kernel(const KgAttnArgs a) {
+    typedef KgT<DT> T;
+    const KgDyn* dyn = a.dyn;
+    if (dyn->active == 0) return;
+    const int M = dyn->n_rows;
+    const int h = blockIdx.x, m = blockIdx.y;
+    if (m >= M) return;
+    const int hd = a.hd, ns = a.nsplit;
+    float mx = -INFINITY;
+    for (int s = 0; s < ns; ++s) mx = fmaxf(mx, a.part_ml[(((size_t)s * a.max_rows + m) * a.H + h) * 2]);
+    for (int dmi = threadIdx.x; dmi < hd; dmi += blockDim.x) {
+        float o = 0.f, l = 0.f;
+        for (int s = 0; s < ns; ++s) {
+            const float* ml = a.part_ml + (((size_t)s * a.max_rows + m) * a.H + h) * 2;
+            const float f = (ml[0] == -INFINITY) ? 0.f : expf(ml[0] - mx);
+            o += f * a.part_o[(((size_t)s * a.max_rows + m) * a.H + h) * hd + dmi];
+            l += f * ml[1];
+        }
+        ((unsigned short*)a.out)[(size_t)m * a.H * hd + (size_t)h * hd + dmi] = T::from_f(o / l);
+    }
+}
+
+template <int DT, int LPR>
+static void launch_lpr(const KgAttnArgs& a, hipStream_t st) {
+    if (a.max_rows == 1) {
+        dim3 grid(a.H, a.nsplit, 1);
+        hipLaunchKernelGGL((kg_attn_kernel<DT, LPR, 1>), grid, dim3(ATT_NW * 64), 0, st, a);
+    } else {
+        dim3 grid(a.H, a.nsplit, (a.max_rows + 7) / 8);
+        hipLaunchKernelGGL((kg_attn_kernel<DT, LPR, 8>), grid, dim3(ATT_NW * 64), 0, st, a);
+    }
+}
+template <int DT>
+static int launch_dt(const KgAttnArgs& a, hipStream_t st) {
+    switch (a.hd) {
+    case 16: launch_lpr<DT, 2>(a, st); break;
+    case 32: launch_lpr<DT, 4>(a, st); break;
+    case 64: launch_lpr<DT, 8>(a, st); break;
+    case 128: launch_lpr<DT, 16>(a, st); break;
+    default: return -1;
+    }
+    if (a.nsplit > 1) {
+        dim3 grid(a.H, a.max_rows);
+        hipLaunchKernelGGL((kg_attn_combine_kernel<DT>), grid, dim3(a.hd < 64 ? 64 : a.hd), 0, st, a);
+    }
+    return 0;
+}
+
+int kg_launch_attn(const KgAttnArgs& a, int dtype, hipStream_t st) {
+    if (a.nsplit < 1 || a.max_rows < 1 || a.max_rows > KG_MAX_ROWS || a.H % a.Hkv != 0) return -1;
+    int rc = (dtype == KG_F16) ? launch_dt<KG_F16>(a, st) : launch_dt<KG_BF16>(a, st);
+    if (rc) return rc;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -1,0 +1,280 @@
+// Small glue kernels: per-pass parameters, embedding gather, standalone RMSNorm, and
+// the device-side state machine of the draft / verify loop
+// (evaluation/inference_kangaroo.py:46-124 of the reference), so that a whole round
+// replays from one captured graph with no host decision inside it.
+#include "kg_common.h"
+#include "kg_kernels.h"
+
+__global__ void kg_set_dyn_kernel(KgDyn* dyn, int active, int n_rows, int pos0) {
+    int i = threadIdx.x;
+    if (i == 0) { dyn->active = active; dyn->n_rows = n_rows; }
+    if (i < KG_MAX_ROWS) dyn->pos[i] = pos0 + i;
+}
+int kg_launch_set_dyn(KgDyn* dyn, int active, int n_rows, int pos0, hipStream_t st) {
+    if (n_rows < 0 || n_rows > KG_MAX_ROWS) return -1;
+    hipLaunchKernelGGL(kg_set_dyn_kernel, dim3(1), dim3(64), 0, st, dyn, active, n_rows, pos0);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// out[m][:] = embed[tokens[pos[m]]][:]   (16-bit elements, d % 8 == 0)
+__global__ void kg_embed_kernel(const KgDyn* dyn, const int* tokens, const kg_u4* embed, int d8, kg_u4* out, int out_stride8) {
+    if (dyn->active == 0) return;
+    const int m = blockIdx.x;
+    if (m >= dyn->n_rows) return;
+    const int tok = tokens[dyn->pos[m]];
+    const kg_u4* src = embed + (size_t)tok * d8;
+    kg_u4* dst = out + (size_t)m * out_stride8;
+    for (int i = threadIdx.x; i < d8; i += blockDim.x) dst[i] = src[i];
+}
+int kg_launch_embed(const KgDyn* dyn, const int* tokens, const void* embed, int d, void* out, int out_stride, hipStream_t st) {
+    if (d % 8 || out_stride % 8) return -1;
+    hipLaunchKernelGGL(kg_embed_kernel, dim3(KG_MAX_ROWS), dim3(256), 0, st, dyn, tokens, (const kg_u4*)embed, d / 8, (kg_u4*)out, out_stride / 8);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int DT>
+__global__ void kg_rmsnorm_kernel(const KgDyn* dyn, const unsigned short* x, int x_stride, const unsigned short* w, float eps, int K,
+                                  unsigned short* out, int out_stride) {
+    typedef KgT<DT> T;
+    if (dyn->active == 0) return;
+    const int m = blockIdx.x;
+    if (m >= dyn->n_rows) return;
+    __shared__ float red[4];
+    const unsigned short* xr = x + (size_t)m * x_stride;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) { float f = T::to_f(xr[i]); ss += f * f; }
+    ss = kg_wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
+    const float rstd = rsqrtf(ss / (float)K + eps);
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        float f = kg_round<DT>(T::to_f(xr[i]) * rstd);
+        out[(size_t)m * out_stride + i] = T::from_f(T::to_f(w[i]) * f);
+    }
+}
+int kg_launch_rmsnorm(const KgDyn* dyn, const void* x, int x_stride, const void* w, float eps, int K, void* out, int out_stride, int dtype, hipStream_t st) {
+    if (dtype == KG_F16)
+        hipLaunchKernelGGL(kg_rmsnorm_kernel<KG_F16>, dim3(KG_MAX_ROWS), dim3(256), 0, st, dyn, (const unsigned short*)x, x_stride, (const unsigned short*)w, eps, K, (unsigned short*)out, out_stride);
+    else
+        hipLaunchKernelGGL(kg_rmsnorm_kernel<KG_BF16>, dim3(KG_MAX_ROWS), dim3(256), 0, st, dyn, (const unsigned short*)x, x_stride, (const unsigned short*)w, eps, K, (unsigned short*)out, out_stride);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---- lm_head partial merge: (max, sum exp(l - max), argmax with lowest-index ties) ----
+struct HeadRec { float mx, sum; int idx; };
+__device__ __forceinline__ void rec_merge(HeadRec& a, const HeadRec& b) {
+    const float M = fmaxf(a.mx, b.mx);
+    const float sa = (a.mx == -INFINITY) ? 0.f : a.sum * expf(a.mx - M);
+    const float sb = (b.mx == -INFINITY) ? 0.f : b.sum * expf(b.mx - M);
+    const bool take_b = (b.mx > a.mx) || (b.mx == a.mx && b.idx < a.idx);
+    a.idx = take_b ? b.idx : a.idx;
+    a.mx = M;
+    a.sum = sa + sb;
+}
+// all 256 threads of the block call this; result valid in every thread
+__device__ HeadRec head_reduce_row(const float* part, int nblocks, float* s_mx, float* s_sum, int* s_idx) {
+    HeadRec r; r.mx = -INFINITY; r.sum = 0.f; r.idx = 0x7fffffff;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+        HeadRec o; o.mx = part[b * 4]; o.sum = part[b * 4 + 1]; o.idx = __float_as_int(part[b * 4 + 2]);
+        rec_merge(r, o);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        HeadRec t; t.mx = __shfl_xor(r.mx, o, 64); t.sum = __shfl_xor(r.sum, o, 64); t.idx = __shfl_xor(r.idx, o, 64);
+        rec_merge(r, t);
+    }
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { s_mx[wave] = r.mx; s_sum[wave] = r.sum; s_idx[wave] = r.idx; }
+    __syncthreads();
+    HeadRec f; f.mx = s_mx[0]; f.sum = s_sum[0]; f.idx = s_idx[0];
+    for (int w = 1; w < nw; ++w) { HeadRec t; t.mx = s_mx[w]; t.sum = s_sum[w]; t.idx = s_idx[w]; rec_merge(f, t); }
+    return f;
+}
+
+__global__ void kg_head_finalize_kernel(const KgDyn* dyn, const float* head_part, int stride, int nblocks, int* tok_out, float* pmax_out) {
+    __shared__ float s_mx[8], s_sum[8]; __shared__ int s_idx[8];
+    if (dyn->active == 0) return;
+    const int M = dyn->n_rows;
+    for (int m = 0; m < M; ++m) {
+        HeadRec r = head_reduce_row(head_part + (size_t)m * stride * 4, nblocks, s_mx, s_sum, s_idx);
+        if (threadIdx.x == 0) { tok_out[m] = r.idx; pmax_out[m] = 1.0f / r.sum; }
+    }
+}
+int kg_launch_head_finalize(const KgDyn* dyn, const float* head_part, int head_part_stride, int nblocks, int max_rows,
+                            int* tok_out, float* pmax_out, hipStream_t st) {
+    (void)max_rows;
+    hipLaunchKernelGGL(kg_head_finalize_kernel, dim3(1), dim3(256), 0, st, dyn, head_part, head_part_stride, nblocks, tok_out, pmax_out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------------
+// Loop state machine.  Flags: KS_ALIVE = the round runs; KS_DRAFT_ON = the adapter +
+// head of the coming step run; dyn_shallow.active = the shallow pass of the coming
+// step runs.  A step's shallow pass runs iff the previous step's adapter ran
+// (the reference breaks before the adapter call, inference_kangaroo.py:74-75).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double kg_thresh(const int* st) {
+    unsigned long long b = ((unsigned long long)(unsigned)st[KS_THRESH_HI] << 32) | (unsigned)st[KS_THRESH_LO];
+    return __builtin_bit_cast(double, b);
+}
+
+__global__ void kg_round_begin_kernel(KgLoopBufs b) {
+    int* st = b.state;
+    if (threadIdx.x != 0) return;
+    const int s = st[KS_START], steps = st[KS_STEPS];
+    const int alive = (st[KS_STOP] == 0) && (s < st[KS_MAX_INFER] - 1 - steps);     // :46
+    st[KS_ALIVE] = alive;
+    st[KS_END] = s + 1;                                                              // :49
+    st[KS_DRAFTED] = 0;
+    st[KS_DRAFT_ON] = alive && (steps > 0);
+    b.dyn_shallow->active = alive;
+    b.dyn_shallow->n_rows = 1;
+    b.dyn_shallow->pos[0] = s;                                                       // token at end_index-1
+}
+
+// after the shallow pass of `step`: adapter rows and positions (:55-61, :70-71)
+__global__ void kg_step_mid_kernel(KgLoopBufs b, int step) {
+    int* st = b.state;
+    const int on = st[KS_DRAFT_ON];
+    const int s = st[KS_START], e = st[KS_END], alen = st[KS_ADAPTER_LEN];
+    const bool patch = (step == 0) && (alen < e - 1);
+    if (threadIdx.x == 0) {
+        KgDyn* d = b.dyn_adapter;
+        d->active = on;
+        if (patch) { d->n_rows = 2; d->pos[0] = s - 1; d->pos[1] = s; }
+        else { d->n_rows = 1; d->pos[0] = e - 1; }
+    }
+    if (step == 0 && on) {
+        // adapter_in rows: [prev_exit, exited[0]] when the adapter cache misses one row, else [exited[0]]
+        const int n16 = b.d * b.elt / 16;
+        const kg_u4* ex = (const kg_u4*)b.exited;
+        const kg_u4* pv = (const kg_u4*)b.prev_exit;
+        kg_u4* ai = (kg_u4*)b.adapter_in;
+        for (int i = threadIdx.x; i < n16; i += blockDim.x) {
+            if (patch) { ai[i] = pv[i]; ai[n16 + i] = ex[i]; }
+            else ai[i] = ex[i];
+        }
+    }
+}
+
+// after the draft head of `step`: token, confidence, next-step switches (:79-83, :74)
+__global__ void kg_step_end_kernel(KgLoopBufs b, int step, const float* head_part, int nblocks) {
+    __shared__ float s_mx[8], s_sum[8]; __shared__ int s_idx[8];
+    int* st = b.state;
+    const int on = st[KS_DRAFT_ON];          // uniform
+    if (!on) {
+        if (threadIdx.x == 0) b.dyn_shallow->active = 0;
+        return;
+    }
+    HeadRec r = head_reduce_row(head_part, nblocks, s_mx, s_sum, s_idx);
+    if (threadIdx.x == 0) {
+        const int e = st[KS_END];
+        const float score = 1.0f / r.sum;                     // softmax max = exp(0) / sum exp(l - max)
+        b.tokens[e] = r.idx;                                  // :80
+        st[KS_END] = e + 1;                                   // :82
+        st[KS_ADAPTER_LEN] = e;                               // adapter cache now covers [0, e)
+        st[KS_SCORE] = __float_as_int(score);
+        st[KS_DRAFTED] = st[KS_DRAFTED] + 1;
+        st[KS_NDRAFT_TOTAL] = st[KS_NDRAFT_TOTAL] + 1;
+        b.head_pmax[step] = score;
+        // next step: its shallow pass always runs; it breaks before the adapter when it
+        // is the last step or the confidence fell below the threshold
+        const int steps = st[KS_STEPS];
+        const bool brk = (step + 1 == steps) || ((double)score < kg_thresh(st));
+        st[KS_DRAFT_ON] = brk ? 0 : 1;
+        b.dyn_shallow->active = 1;
+        b.dyn_shallow->n_rows = 1;
+        b.dyn_shallow->pos[0] = e;                            // the token just drafted
+    }
+}
+
+// rows of the verify pass: positions s .. e-1 (:86-89)
+__global__ void kg_verify_begin_kernel(KgLoopBufs b) {
+    int* st = b.state;
+    const int i = threadIdx.x;
+    const int s = st[KS_START], e = st[KS_END];
+    KgDyn* d = b.dyn_verify;
+    if (i == 0) { d->active = st[KS_ALIVE]; d->n_rows = e - s; }
+    if (i < KG_MAX_ROWS) d->pos[i] = s + i;
+}
+
+// greedy accept / reject, cache rollback by length (:91-119)
+__global__ void kg_accept_kernel(KgLoopBufs b, const float* head_part, int stride, int nblocks) {
+    __shared__ float s_mx[8], s_sum[8]; __shared__ int s_idx[8];
+    __shared__ int s_tok[KG_MAX_ROWS];
+    int* st = b.state;
+    if (st[KS_ALIVE] == 0) return;
+    const int s = st[KS_START], e = st[KS_END];
+    const int q = e - s;
+    for (int m = 0; m < q; ++m) {
+        HeadRec r = head_reduce_row(head_part + (size_t)m * stride * 4, nblocks, s_mx, s_sum, s_idx);
+        if (threadIdx.x == 0) { s_tok[m] = r.idx; b.head_tok[m] = r.idx; }
+    }
+    __syncthreads();
+    // keep the last early-exit row for the adapter's missing-cache patch of the next round (:58)
+    {
+        const int n16 = b.d * b.elt / 16;
+        const kg_u4* ex = (const kg_u4*)b.exited + (size_t)(q - 1) * n16;
+        kg_u4* pv = (kg_u4*)b.prev_exit;
+        for (int i = threadIdx.x; i < n16; i += blockDim.x) pv[i] = ex[i];
+    }
+    if (threadIdx.x == 0) {
+        const int eos = st[KS_EOS];
+        int snew = s, stop = 0;
+        for (int i = 0; i < q; ++i) {
+            const int o = s_tok[i];
+            if (i == q - 1 || o == eos || o != b.tokens[s + 1 + i]) {                 // :97
+                b.tokens[s + 1 + i] = o;                                              // :98
+                snew = s + 1 + i;                                                     // :99
+                stop = (o == eos);                                                    // :100
+                break;
+            }
+        }
+        const int r = st[KS_ROUND];
+        st[KS_HDR + 2 * r] = snew - s;                                                // :104
+        st[KS_HDR + 2 * r + 1] = q - 1;
+        st[KS_ROUND] = r + 1;
+        st[KS_START] = snew;
+        st[KS_STOP] = stop;
+        st[KS_Q_PREV] = q;
+        // base caches: slot == position, everything at slots >= snew is dead and gets
+        // overwritten; the adapter cache is tracked by length (:114-118)
+        if (st[KS_ADAPTER_LEN] > snew) st[KS_ADAPTER_LEN] = snew;
+    }
+}
+
+// ---- vanilla greedy decode: one token per graph replay ----
+__global__ void kg_vanilla_begin_kernel(KgLoopBufs b) {
+    int* st = b.state;
+    if (threadIdx.x != 0) return;
+    const int s = st[KS_START];
+    const int alive = (st[KS_STOP] == 0) && (s + 1 < st[KS_MAX_INFER]);
+    st[KS_ALIVE] = alive;
+    b.dyn_shallow->active = alive;
+    b.dyn_shallow->n_rows = 1;
+    b.dyn_shallow->pos[0] = s;
+}
+__global__ void kg_vanilla_end_kernel(KgLoopBufs b, const float* head_part, int nblocks) {
+    __shared__ float s_mx[8], s_sum[8]; __shared__ int s_idx[8];
+    int* st = b.state;
+    if (st[KS_ALIVE] == 0) return;
+    HeadRec r = head_reduce_row(head_part, nblocks, s_mx, s_sum, s_idx);
+    if (threadIdx.x == 0) {
+        const int s = st[KS_START];
+        b.tokens[s + 1] = r.idx;
+        st[KS_START] = s + 1;
+        st[KS_STOP] = (r.idx == st[KS_EOS]);
+        st[KS_ROUND] = st[KS_ROUND] + 1;
+    }
+}
+
+#define KG_L1(k, ...) do { hipLaunchKernelGGL(k, dim3(1), dim3(256), 0, st, __VA_ARGS__); return hipGetLastError() == hipSuccess ? 0 : -2; } while (0)
+int kg_launch_round_begin(const KgLoopBufs& b, hipStream_t st) { KG_L1(kg_round_begin_kernel, b); }
+int kg_launch_step_mid(const KgLoopBufs& b, int step, hipStream_t st) { KG_L1(kg_step_mid_kernel, b, step); }
+int kg_launch_step_end(const KgLoopBufs& b, int step, const float* head_part, int nblocks, hipStream_t st) { KG_L1(kg_step_end_kernel, b, step, head_part, nblocks); }
+int kg_launch_verify_begin(const KgLoopBufs& b, hipStream_t st) { KG_L1(kg_verify_begin_kernel, b); }
+int kg_launch_accept(const KgLoopBufs& b, const float* head_part, int stride, int nblocks, hipStream_t st) { KG_L1(kg_accept_kernel, b, head_part, stride, nblocks); }
+int kg_launch_vanilla_begin(const KgLoopBufs& b, hipStream_t st) { KG_L1(kg_vanilla_begin_kernel, b); }
+int kg_launch_vanilla_end(const KgLoopBufs& b, const float* head_part, int nblocks, hipStream_t st) { KG_L1(kg_vanilla_end_kernel, b, head_part, nblocks); }

@@ -1,0 +1,649 @@
+// Host side of libkangaroo_hip.so: C ABI, pass composition, graph capture and the
+// generate loops.  All device buffers are caller-owned (see include/kangaroo_hip.h).
+#include "../../include/kangaroo_hip.h"
+#include "kg_common.h"
+#include "kg_kernels.h"
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+
+static thread_local std::string g_err;
+void kg_set_error(const char* what, hipError_t e) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+}
+static int fail(int code, const char* msg) { g_err = msg; return code; }
+#define KG_TRY(x) do { int rc_ = (x); if (rc_ != 0) { if (g_err.empty()) g_err = #x; return rc_; } } while (0)
+
+extern "C" int kg_version(void) { return 1; }
+extern "C" const char* kg_last_error(void) { return g_err.c_str(); }
+
+static bool g_init = false;
+static int g_ncu = 256;
+static void kg_init_once() {
+    if (g_init) return;
+    kg_linear_init();
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_ncu = p.multiProcessorCount;
+    g_init = true;
+}
+
+struct kg_session {
+    kg_shape sh;
+    kg_weights w;
+    std::vector<kg_layer_weights> layers;
+    kg_buffers buf;
+    int elt;
+    int q_dim, kv_dim;
+    // workspace carve-up
+    int* state; int* tokens;
+    KgDyn *dyn_shallow, *dyn_adapter, *dyn_verify, *dyn_call;
+    char *h, *h2, *xq, *attn_out, *act, *exited, *prev_exit, *adapter_in, *adapter_h, *hs_early;
+    float *part_o, *part_ml, *head_part;
+    int* head_tok; float* head_pmax;
+    int head_part_stride;
+    int prefill_rows;
+    // tuning
+    int vec_bpc, mfma_bpc, vec_waves, mfma_waves, attn_nsplit;
+    // graphs
+    hipStream_t own_stream;
+    hipGraphExec_t round_graph; int round_graph_steps;
+    hipGraphExec_t vanilla_graph;
+    int* host_state; hipEvent_t ev[2]; hipEvent_t ev_in, ev_t0, ev_t1, ev_t2;
+};
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Carver {
+    char* base; size_t off;
+    template <class T> T* take(size_t n) { off = align_up(off, 256); T* p = base ? (T*)(base + off) : nullptr; off += n * sizeof(T); return p; }
+};
+
+static int prefill_rows_for(const kg_shape* sh) {
+    // X rows of one chunk must fit LDS beside the partial-sum slots (see kg_linear_smem)
+    size_t per_row = (size_t)sh->hidden_size * 2 + 32;
+    size_t avail = 160 * 1024 - 2 * 8 * 256 * 4;
+    return (16 * per_row <= avail) ? 16 : 8;
+}
+
+static void carve(kg_session* s, Carver& c, const kg_shape* sh, int t_max) {
+    const size_t d = sh->hidden_size, F = sh->intermediate_size, qd = (size_t)sh->num_heads * sh->head_dim;
+    const size_t e = 2, R = KG_MAX_ROWS;
+    const int max_rounds = t_max + 8;
+    int* state = c.take<int>(KS_HDR + 2 * (size_t)max_rounds);
+    int* tokens = c.take<int>((size_t)t_max + 64);
+    KgDyn* dyn = c.take<KgDyn>(4);
+    char* h = c.take<char>(R * d * e);
+    char* h2 = c.take<char>(R * d * e);
+    char* xq = c.take<char>(R * qd * e);
+    char* attn_out = c.take<char>(R * qd * e);
+    char* act = c.take<char>(R * F * e);
+    char* exited = c.take<char>(R * d * e);
+    char* prev_exit = c.take<char>(d * e);
+    char* adapter_in = c.take<char>(2 * d * e);
+    char* adapter_h = c.take<char>(R * d * e);
+    char* hs_early = c.take<char>((size_t)t_max * d * e);
+    const int nsplit_max = 32;
+    float* part_o = c.take<float>((size_t)nsplit_max * R * qd);
+    float* part_ml = c.take<float>((size_t)nsplit_max * R * sh->num_heads * 2);
+    const int hp_stride = (sh->vocab_size + 15) / 16;
+    float* head_part = c.take<float>((size_t)R * hp_stride * 4);
+    int* head_tok = c.take<int>(R);
+    float* head_pmax = c.take<float>(R);
+    if (s) {
+        s->state = state; s->tokens = tokens;
+        s->dyn_shallow = dyn; s->dyn_adapter = dyn + 1; s->dyn_verify = dyn + 2; s->dyn_call = dyn + 3;
+        s->h = h; s->h2 = h2; s->xq = xq; s->attn_out = attn_out; s->act = act; s->exited = exited;
+        s->prev_exit = prev_exit; s->adapter_in = adapter_in; s->adapter_h = adapter_h; s->hs_early = hs_early;
+        s->part_o = part_o; s->part_ml = part_ml; s->head_part = head_part; s->head_part_stride = hp_stride;
+        s->head_tok = head_tok; s->head_pmax = head_pmax;
+    }
+}
+
+extern "C" size_t kg_workspace_bytes(const kg_shape* shape, int t_max) {
+    Carver c{nullptr, 0};
+    carve(nullptr, c, shape, t_max);
+    return align_up(c.off, 256);
+}
+
+extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weights, const kg_buffers* buffers, kg_session** out) {
+    g_err.clear();
+    if (!shape || !weights || !buffers || !out) return fail(-1, "null argument");
+    if (shape->hidden_size % 32 || shape->intermediate_size % 32) return fail(-1, "hidden_size and intermediate_size must be multiples of 32");
+    if (shape->head_dim != 16 && shape->head_dim != 32 && shape->head_dim != 64 && shape->head_dim != 128) return fail(-1, "head_dim must be 16, 32, 64 or 128");
+    if (shape->num_heads % shape->num_kv_heads) return fail(-1, "num_heads must be a multiple of num_kv_heads");
+    if (shape->exit_layer < 1 || shape->exit_layer >= shape->num_layers) return fail(-1, "exit_layer must be in [1, num_layers)");
+    if (buffers->t_max > shape->max_positions) return fail(-1, "t_max exceeds the RoPE table");
+    if (buffers->workspace_bytes < kg_workspace_bytes(shape, buffers->t_max)) return fail(-1, "workspace too small");
+    kg_init_once();
+    kg_session* s = new kg_session();
+    s->sh = *shape; s->w = *weights; s->buf = *buffers;
+    s->layers.assign(weights->layers, weights->layers + shape->num_layers);
+    s->w.layers = s->layers.data();
+    s->elt = 2;
+    s->q_dim = shape->num_heads * shape->head_dim;
+    s->kv_dim = shape->num_kv_heads * shape->head_dim;
+    Carver c{(char*)buffers->workspace, 0};
+    carve(s, c, shape, buffers->t_max);
+    s->prefill_rows = prefill_rows_for(shape);
+    s->vec_bpc = 4; s->mfma_bpc = 2; s->vec_waves = 8; s->mfma_waves = 8;
+    s->attn_nsplit = 8;
+    s->round_graph = nullptr; s->round_graph_steps = -1; s->vanilla_graph = nullptr;
+    if (hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking) != hipSuccess) { delete s; return fail(-2, "hipStreamCreate failed"); }
+    if (hipHostMalloc((void**)&s->host_state, 4 * 64 * sizeof(int)) != hipSuccess) { delete s; return fail(-2, "hipHostMalloc failed"); }
+    hipEventCreateWithFlags(&s->ev[0], hipEventDisableTiming);
+    hipEventCreateWithFlags(&s->ev[1], hipEventDisableTiming);
+    hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
+    hipEventCreate(&s->ev_t0); hipEventCreate(&s->ev_t1); hipEventCreate(&s->ev_t2);
+    *out = s;
+    return 0;
+}
+
+extern "C" int kg_session_destroy(kg_session* s) {
+    if (!s) return 0;
+    hipStreamSynchronize(s->own_stream);
+    if (s->round_graph) hipGraphExecDestroy(s->round_graph);
+    if (s->vanilla_graph) hipGraphExecDestroy(s->vanilla_graph);
+    hipEventDestroy(s->ev[0]); hipEventDestroy(s->ev[1]); hipEventDestroy(s->ev_in);
+    hipEventDestroy(s->ev_t0); hipEventDestroy(s->ev_t1); hipEventDestroy(s->ev_t2);
+    hipHostFree(s->host_state);
+    hipStreamDestroy(s->own_stream);
+    delete s;
+    return 0;
+}
+
+extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
+    if (!s || !key) return fail(-1, "null argument");
+    std::string k(key);
+    if (value < 1) return fail(-1, "value must be >= 1");
+    if (k == "vec_blocks_per_cu") s->vec_bpc = value;
+    else if (k == "mfma_blocks_per_cu") s->mfma_bpc = value;
+    else if (k == "vec_waves") { if (value > 8) return fail(-1, "waves <= 8"); s->vec_waves = value; }
+    else if (k == "mfma_waves") { if (value > 8) return fail(-1, "waves <= 8"); s->mfma_waves = value; }
+    else if (k == "attn_nsplit") { if (value > 32) return fail(-1, "nsplit <= 32"); s->attn_nsplit = value; }
+    else return fail(-1, "unknown key");
+    // graphs bake the launch geometry in
+    if (s->round_graph) { hipGraphExecDestroy(s->round_graph); s->round_graph = nullptr; s->round_graph_steps = -1; }
+    if (s->vanilla_graph) { hipGraphExecDestroy(s->vanilla_graph); s->vanilla_graph = nullptr; }
+    return 0;
+}
+
+extern "C" void* kg_session_ptr(kg_session* s, const char* name) {
+    if (!s || !name) return nullptr;
+    std::string k(name);
+    if (k == "tokens") return s->tokens;
+    if (k == "state") return s->state;
+    if (k == "hs_early") return s->hs_early;
+    if (k == "head_tok") return s->head_tok;
+    if (k == "head_pmax") return s->head_pmax;
+    return nullptr;
+}
+
+// ---------------------------------------------------------------------------------
+// pass composition
+// ---------------------------------------------------------------------------------
+static int grid_for(const kg_session* s, int N, int max_rows) {
+    const int G = (N + 15) / 16;
+    const int per = (max_rows == 1) ? s->vec_bpc : s->mfma_bpc;
+    int nb = g_ncu * per;
+    return nb < G ? nb : G;
+}
+static int waves_for(const kg_session* s, int max_rows) { return max_rows == 1 ? s->vec_waves : s->mfma_waves; }
+
+static KgLinArgs lin_base(const KgDyn* dyn, const void* W, int N, int K, const void* x, int x_stride) {
+    KgLinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.W = W; a.N = N; a.K = K; a.dyn = dyn; a.x = x; a.x_stride = x_stride;
+    return a;
+}
+
+// One decoder layer on the rows described by dyn.  lw.wgu == NULL: attention half only
+// (the adapter layer, kangaroo/adapter.py:292-304).  h_in / h_out may alias.
+static int run_layer(kg_session* s, const kg_layer_weights& lw, void* kc, void* vc, const KgDyn* dyn, int max_rows,
+                     const void* h_in, void* h_out, hipStream_t st) {
+    const kg_shape& sh = s->sh;
+    const int d = sh.hidden_size, F = sh.intermediate_size, dt = sh.dtype;
+    const int nw = waves_for(s, max_rows);
+    {
+        KgLinArgs a = lin_base(dyn, lw.wqkv, s->q_dim + 2 * s->kv_dim, d, h_in, d);
+        a.norm_w = lw.norm1; a.eps = sh.rms_eps;
+        a.q_out = s->xq; a.k_cache = kc; a.v_cache = vc;
+        a.rope_cos = s->w.rope_cos; a.rope_sin = s->w.rope_sin;
+        a.head_dim = sh.head_dim; a.q_dim = s->q_dim; a.kv_dim = s->kv_dim; a.t_max = s->buf.t_max;
+        KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_RMSNORM, EPI_ROPE_KV, grid_for(s, a.N, max_rows), nw, st));
+    }
+    {
+        KgAttnArgs a;
+        memset(&a, 0, sizeof(a));
+        a.dyn = dyn; a.q = s->xq; a.k_cache = kc; a.v_cache = vc;
+        a.H = sh.num_heads; a.Hkv = sh.num_kv_heads; a.hd = sh.head_dim; a.t_max = s->buf.t_max;
+        a.nsplit = s->attn_nsplit; a.part_o = s->part_o; a.part_ml = s->part_ml; a.out = s->attn_out; a.max_rows = max_rows;
+        KG_TRY(kg_launch_attn(a, dt, st));
+    }
+    const bool attn_only = (lw.wgu == nullptr);
+    void* h_mid = h_out;
+    {
+        KgLinArgs a = lin_base(dyn, lw.wo, d, s->q_dim, s->attn_out, s->q_dim);
+        a.out = h_mid; a.out_stride = d; a.resid = h_in; a.resid_stride = d;
+        KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_NONE, EPI_RESID, grid_for(s, a.N, max_rows), nw, st));
+    }
+    if (attn_only) return 0;
+    {
+        KgLinArgs a = lin_base(dyn, lw.wgu, 2 * F, d, h_mid, d);
+        a.norm_w = lw.norm2; a.eps = sh.rms_eps;
+        a.out = s->act; a.out_stride = F;
+        KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_RMSNORM, EPI_SILU_MUL, grid_for(s, a.N, max_rows), nw, st));
+    }
+    {
+        KgLinArgs a = lin_base(dyn, lw.wdown, d, F, s->act, F);
+        a.out = h_out; a.out_stride = d; a.resid = h_mid; a.resid_stride = d;
+        KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_NONE, EPI_RESID, grid_for(s, a.N, max_rows), nw, st));
+    }
+    return 0;
+}
+
+static void* layer_k(kg_session* s, int l) { return (char*)s->buf.k_cache + (size_t)l * s->sh.num_kv_heads * s->buf.t_max * s->sh.head_dim * s->elt; }
+static void* layer_v(kg_session* s, int l) { return (char*)s->buf.v_cache + (size_t)l * s->sh.num_kv_heads * s->buf.t_max * s->sh.head_dim * s->elt; }
+
+// lm_head on rows of x; prologue RMSNorm with norm_w when given.  Leaves per-block
+// (max, sum, argmax) records in head_part; returns the block count through *nblocks.
+static int run_head(kg_session* s, const KgDyn* dyn, int max_rows, const void* x, int x_last_row, const void* norm_w,
+                    void* logits_out, int* nblocks, hipStream_t st) {
+    KgLinArgs a = lin_base(dyn, s->w.lm_head, s->sh.vocab_size, s->sh.hidden_size, x, s->sh.hidden_size);
+    a.x_last_row = x_last_row;
+    a.norm_w = norm_w; a.eps = s->sh.rms_eps;
+    a.head_part = s->head_part; a.head_part_stride = s->head_part_stride;
+    a.logits_out = logits_out; a.logits_stride = s->sh.vocab_size;
+    int nb = grid_for(s, a.N, max_rows);
+    *nblocks = nb;
+    return kg_launch_linear(a, s->sh.dtype, max_rows, norm_w ? PRO_RMSNORM : PRO_NONE, EPI_HEAD, nb, waves_for(s, max_rows), st);
+}
+
+static KgLoopBufs loop_bufs(kg_session* s) {
+    KgLoopBufs b;
+    b.state = s->state; b.tokens = s->tokens;
+    b.dyn_shallow = s->dyn_shallow; b.dyn_adapter = s->dyn_adapter; b.dyn_verify = s->dyn_verify;
+    b.exited = s->exited; b.prev_exit = s->prev_exit; b.adapter_in = s->adapter_in;
+    b.head_tok = s->head_tok; b.head_pmax = s->head_pmax;
+    b.d = s->sh.hidden_size; b.elt = s->elt;
+    return b;
+}
+
+// ---------------------------------------------------------------------------------
+// model-level entry points
+// ---------------------------------------------------------------------------------
+extern "C" int kg_set_tokens(kg_session* s, const int32_t* tokens_host, int pos0, int n, void* stream) {
+    g_err.clear();
+    if (!s || !tokens_host || pos0 < 0 || n < 0 || pos0 + n > s->buf.t_max) return fail(-1, "bad token range");
+    KG_CHECK_HIP(hipMemcpyAsync(s->tokens + pos0, tokens_host, (size_t)n * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int kg_forward_layers(kg_session* s, int layer_begin, int layer_end, const void* x_in, int pos0, int n_rows,
+                                 void* h_out, void* stream) {
+    g_err.clear();
+    hipStream_t st = (hipStream_t)stream;
+    if (!s || !h_out) return fail(-1, "null argument");
+    if (layer_begin < 0 || layer_end > s->sh.num_layers || layer_begin >= layer_end) return fail(-1, "bad layer range");
+    if (n_rows < 1 || n_rows > KG_MAX_ROWS) return fail(-1, "n_rows must be in [1, 16]");
+    if (pos0 < 0 || pos0 + n_rows > s->buf.t_max) return fail(-1, "positions exceed the cache");
+    const int d = s->sh.hidden_size;
+    const int max_rows = (n_rows == 1) ? 1 : n_rows;
+    if (max_rows > 1 && kg_linear_smem(1, max_rows, d, s->mfma_waves) > 160 * 1024) return fail(-3, "rows x hidden_size exceed LDS; use fewer rows per call");
+    KG_TRY(kg_launch_set_dyn(s->dyn_call, 1, n_rows, pos0, st));
+    const void* cur = x_in;
+    if (!x_in) {
+        KG_TRY(kg_launch_embed(s->dyn_call, s->tokens, s->w.embed, d, s->h, d, st));
+        cur = s->h;
+    }
+    for (int l = layer_begin; l < layer_end; ++l) {
+        void* dst = (l == layer_end - 1) ? h_out : (void*)s->h;
+        KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_call, max_rows, cur, dst, st));
+        cur = dst;
+    }
+    return 0;
+}
+
+extern "C" int kg_final_norm(kg_session* s, const void* x, int n_rows, void* out, void* stream) {
+    g_err.clear();
+    if (!s || !x || !out || n_rows < 1 || n_rows > KG_MAX_ROWS) return fail(-1, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    KG_TRY(kg_launch_set_dyn(s->dyn_call, 1, n_rows, 0, st));
+    return kg_launch_rmsnorm(s->dyn_call, x, s->sh.hidden_size, s->w.final_norm, s->sh.rms_eps, s->sh.hidden_size, out, s->sh.hidden_size, s->sh.dtype, st);
+}
+
+extern "C" int kg_adapter_forward(kg_session* s, const void* x_in, int pos0, int n_rows, void* h_out, void* stream) {
+    g_err.clear();
+    hipStream_t st = (hipStream_t)stream;
+    if (!s || !x_in || !h_out) return fail(-1, "null argument");
+    if (n_rows < 1 || n_rows > KG_MAX_ROWS) return fail(-1, "n_rows must be in [1, 16]");
+    if (pos0 < 0 || pos0 + n_rows > s->buf.t_max) return fail(-1, "positions exceed the cache");
+    const int d = s->sh.hidden_size;
+    const int max_rows = (n_rows == 1) ? 1 : n_rows;
+    if (max_rows > 1 && kg_linear_smem(1, max_rows, d, s->mfma_waves) > 160 * 1024) return fail(-3, "rows x hidden_size exceed LDS; use fewer rows per call");
+    KG_TRY(kg_launch_set_dyn(s->dyn_call, 1, n_rows, pos0, st));
+    KG_TRY(run_layer(s, s->w.adapter, s->buf.ak_cache, s->buf.av_cache, s->dyn_call, max_rows, x_in, s->adapter_h, st));
+    return kg_launch_rmsnorm(s->dyn_call, s->adapter_h, d, s->w.adapter_norm, s->sh.rms_eps, d, h_out, d, s->sh.dtype, st);
+}
+
+extern "C" int kg_head_logits(kg_session* s, const void* x, int n_rows, void* logits_out, int* argmax_out, float* pmax_out, void* stream) {
+    g_err.clear();
+    hipStream_t st = (hipStream_t)stream;
+    if (!s || !x || n_rows < 1 || n_rows > KG_MAX_ROWS) return fail(-1, "bad argument");
+    KG_TRY(kg_launch_set_dyn(s->dyn_call, 1, n_rows, 0, st));
+    int nb = 0;
+    KG_TRY(run_head(s, s->dyn_call, n_rows == 1 ? 1 : n_rows, x, 0, nullptr, logits_out, &nb, st));
+    if (argmax_out || pmax_out) {
+        KG_TRY(kg_launch_head_finalize(s->dyn_call, s->head_part, s->head_part_stride, nb, n_rows,
+                                       argmax_out ? argmax_out : s->head_tok, pmax_out ? pmax_out : s->head_pmax, st));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// generate: prefill + graph-replayed rounds
+// ---------------------------------------------------------------------------------
+static int enqueue_round(kg_session* s, int steps, hipStream_t st) {
+    const kg_shape& sh = s->sh;
+    const int d = sh.hidden_size, L = sh.exit_layer, N = sh.num_layers;
+    const size_t rowb = (size_t)d * s->elt;
+    KgLoopBufs b = loop_bufs(s);
+    KG_TRY(kg_launch_round_begin(b, st));
+    for (int k = 0; k <= steps; ++k) {
+        // shallow pass on the newest token -> exited[k]
+        KG_TRY(kg_launch_embed(s->dyn_shallow, s->tokens, s->w.embed, d, s->h, d, st));
+        const void* cur = s->h;
+        for (int l = 0; l < L; ++l) {
+            void* dst = (l == L - 1) ? (void*)(s->exited + k * rowb) : (void*)s->h;
+            KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_shallow, 1, cur, dst, st));
+            cur = dst;
+        }
+        if (k == steps) break;
+        KG_TRY(kg_launch_step_mid(b, k, st));
+        if (k == 0) {
+            KG_TRY(run_layer(s, s->w.adapter, s->buf.ak_cache, s->buf.av_cache, s->dyn_adapter, 2, s->adapter_in, s->adapter_h, st));
+        } else {
+            KG_TRY(run_layer(s, s->w.adapter, s->buf.ak_cache, s->buf.av_cache, s->dyn_adapter, 1, s->exited + k * rowb, s->adapter_h, st));
+        }
+        int nb = 0;
+        KG_TRY(run_head(s, s->dyn_adapter, 1, s->adapter_h, 1, s->w.adapter_norm, nullptr, &nb, st));
+        KG_TRY(kg_launch_step_end(b, k, s->head_part, nb, st));
+    }
+    KG_TRY(kg_launch_verify_begin(b, st));
+    const int vrows = steps + 1 > 1 ? steps + 1 : 2;
+    const void* cur = s->exited;
+    for (int l = L; l < N; ++l) {
+        KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_verify, vrows, cur, s->h2, st));
+        cur = s->h2;
+    }
+    int nb = 0;
+    KG_TRY(run_head(s, s->dyn_verify, vrows, s->h2, 0, s->w.final_norm, nullptr, &nb, st));
+    KG_TRY(kg_launch_accept(b, s->head_part, s->head_part_stride, nb, st));
+    return 0;
+}
+
+static int enqueue_vanilla(kg_session* s, hipStream_t st) {
+    const kg_shape& sh = s->sh;
+    KgLoopBufs b = loop_bufs(s);
+    KG_TRY(kg_launch_vanilla_begin(b, st));
+    KG_TRY(kg_launch_embed(s->dyn_shallow, s->tokens, s->w.embed, sh.hidden_size, s->h, sh.hidden_size, st));
+    for (int l = 0; l < sh.num_layers; ++l)
+        KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_shallow, 1, s->h, s->h, st));
+    int nb = 0;
+    KG_TRY(run_head(s, s->dyn_shallow, 1, s->h, 0, s->w.final_norm, nullptr, &nb, st));
+    KG_TRY(kg_launch_vanilla_end(b, s->head_part, nb, st));
+    return 0;
+}
+
+static int capture(kg_session* s, int mode, int steps, hipGraphExec_t* out) {
+    hipStream_t st = s->own_stream;
+    hipGraph_t g = nullptr;
+    KG_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+    int rc = (mode == 0) ? enqueue_round(s, steps, st) : enqueue_vanilla(s, st);
+    hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc != 0) { if (g) hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) { kg_set_error("hipStreamEndCapture", e); return -2; }
+    e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) { kg_set_error("hipGraphInstantiate", e); return -2; }
+    return 0;
+}
+
+// Prefill: all layers over the prompt in chunks of prefill_rows rows; keeps the input of
+// the exit layer for the adapter's cache (inference_kangaroo.py:30-38).
+static int prefill(kg_session* s, int T0, bool with_adapter, hipStream_t st) {
+    const kg_shape& sh = s->sh;
+    const int d = sh.hidden_size, L = sh.exit_layer, N = sh.num_layers, C = s->prefill_rows;
+    const size_t rowb = (size_t)d * s->elt;
+    int last_n = 1;
+    for (int c0 = 0; c0 < T0; c0 += C) {
+        const int n = (T0 - c0 < C) ? (T0 - c0) : C;
+        last_n = n;
+        const int max_rows = C;
+        KG_TRY(kg_launch_set_dyn(s->dyn_call, 1, n, c0, st));
+        KG_TRY(kg_launch_embed(s->dyn_call, s->tokens, s->w.embed, d, s->h, d, st));
+        const void* cur = s->h;
+        for (int l = 0; l < N; ++l) {
+            void* dst = (l == L - 1) ? (void*)(s->hs_early + (size_t)c0 * rowb) : (void*)s->h;
+            KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_call, max_rows, cur, dst, st));
+            cur = dst;
+        }
+    }
+    (void)last_n;
+    // first new token from the last row's logits (:33-34); dyn_call still describes the last chunk
+    int nb = 0;
+    KG_TRY(run_head(s, s->dyn_call, 1, s->h, 1, s->w.final_norm, nullptr, &nb, st));
+    KG_TRY(kg_launch_vanilla_end(loop_bufs(s), s->head_part, nb, st));
+    if (with_adapter) {
+        for (int c0 = 0; c0 < T0; c0 += C) {
+            const int n = (T0 - c0 < C) ? (T0 - c0) : C;
+            KG_TRY(kg_launch_set_dyn(s->dyn_call, 1, n, c0, st));
+            KG_TRY(run_layer(s, s->w.adapter, s->buf.ak_cache, s->buf.av_cache, s->dyn_call, C, s->hs_early + (size_t)c0 * rowb, s->h2, st));
+        }
+    }
+    return 0;
+}
+
+extern "C" int kg_generate(kg_session* s, int mode, const int32_t* prompt_host, int context_length, int max_new_tokens,
+                           int max_length, int steps, double threshold, int eos_token_id,
+                           int32_t* out_tokens_host, int32_t* accept_log_host, int accept_log_capacity,
+                           kg_gen_result* result, void* stream) {
+    g_err.clear();
+    if (!s || !prompt_host || !out_tokens_host || !result) return fail(-1, "null argument");
+    if (mode != 0 && mode != 1) return fail(-1, "mode must be 0 (kangaroo) or 1 (vanilla)");
+    if (context_length < 1 || max_length > s->buf.t_max || context_length >= max_length) return fail(-1, "context_length / max_length out of range");
+    if (mode == 0 && (steps < 0 || steps + 1 > KG_MAX_ROWS - 1)) return fail(-1, "steps out of range");
+    if (max_new_tokens < 1) return fail(-1, "max_new_tokens must be >= 1");
+    hipStream_t st = s->own_stream;
+    // order after whatever the caller queued on its stream
+    KG_CHECK_HIP(hipEventRecord(s->ev_in, (hipStream_t)stream));
+    KG_CHECK_HIP(hipStreamWaitEvent(st, s->ev_in, 0));
+
+    if (mode == 0 && (s->round_graph == nullptr || s->round_graph_steps != steps)) {
+        if (s->round_graph) { hipGraphExecDestroy(s->round_graph); s->round_graph = nullptr; }
+        KG_TRY(capture(s, 0, steps, &s->round_graph));
+        s->round_graph_steps = steps;
+    }
+    if (mode == 1 && s->vanilla_graph == nullptr) KG_TRY(capture(s, 1, 0, &s->vanilla_graph));
+
+    const int T0 = context_length;
+    const int max_infer = (max_length < T0 + max_new_tokens) ? max_length : (T0 + max_new_tokens);
+    int* hs = s->host_state;          // [0..63] init block, [64..127], [128..191] read-back slots
+    memset(hs, 0, 64 * sizeof(int));
+    hs[KS_START] = T0 - 1;            // the prefill's head step moves it to T0
+    hs[KS_END] = T0;
+    hs[KS_ADAPTER_LEN] = T0;
+    hs[KS_ALIVE] = 1;
+    hs[KS_CTX] = T0;
+    hs[KS_MAX_INFER] = max_infer;
+    hs[KS_STEPS] = steps;
+    hs[KS_EOS] = -1;                  // the prefill token never stops the loop (:34)
+    unsigned long long tb; memcpy(&tb, &threshold, 8);
+    hs[KS_THRESH_LO] = (int)(unsigned)(tb & 0xffffffffu);
+    hs[KS_THRESH_HI] = (int)(unsigned)(tb >> 32);
+    KG_CHECK_HIP(hipMemcpyAsync(s->state, hs, KS_HDR * sizeof(int), hipMemcpyHostToDevice, st));
+    KG_CHECK_HIP(hipMemcpyAsync(s->tokens, prompt_host, (size_t)T0 * sizeof(int), hipMemcpyHostToDevice, st));
+
+    KG_CHECK_HIP(hipEventRecord(s->ev_t0, st));
+    KG_TRY(prefill(s, T0, mode == 0, st));
+    // now arm the real eos / reset the round counter
+    hs[32 + 0] = eos_token_id; hs[32 + 1] = 0;
+    KG_CHECK_HIP(hipMemcpyAsync(s->state + KS_EOS, hs + 32, sizeof(int), hipMemcpyHostToDevice, st));
+    KG_CHECK_HIP(hipMemcpyAsync(s->state + KS_ROUND, hs + 33, sizeof(int), hipMemcpyHostToDevice, st));
+    KG_CHECK_HIP(hipMemcpyAsync(s->state + KS_STOP, hs + 33, sizeof(int), hipMemcpyHostToDevice, st));
+    KG_CHECK_HIP(hipEventRecord(s->ev_t1, st));
+
+    hipGraphExec_t ge = (mode == 0) ? s->round_graph : s->vanilla_graph;
+    auto finished = [&](const int* v) {
+        if (v[KS_STOP]) return true;
+        if (mode == 0) return !(v[KS_START] < max_infer - 1 - steps);
+        return !(v[KS_START] + 1 < max_infer);
+    };
+    int* slot[2] = {hs + 64, hs + 128};
+    auto launch = [&](int i) -> int {
+        KG_CHECK_HIP(hipGraphLaunch(ge, st));
+        KG_CHECK_HIP(hipMemcpyAsync(slot[i], s->state, KS_HDR * sizeof(int), hipMemcpyDeviceToHost, st));
+        KG_CHECK_HIP(hipEventRecord(s->ev[i], st));
+        return 0;
+    };
+    // state right after the prefill decides whether any round runs at all
+    KG_CHECK_HIP(hipMemcpyAsync(slot[0], s->state, KS_HDR * sizeof(int), hipMemcpyDeviceToHost, st));
+    KG_CHECK_HIP(hipEventRecord(s->ev[0], st));
+    KG_CHECK_HIP(hipEventSynchronize(s->ev[0]));
+    int final_slot = 0;
+    if (!finished(slot[0])) {
+        // keep one replay queued ahead of the one being waited for
+        int cur = 0;
+        KG_TRY(launch(cur));
+        const int guard = 2 * s->buf.t_max + 16;
+        for (int it = 0; it < guard; ++it) {
+            KG_TRY(launch(1 - cur));
+            KG_CHECK_HIP(hipEventSynchronize(s->ev[cur]));
+            if (finished(slot[cur])) { final_slot = cur; break; }
+            cur = 1 - cur;
+            final_slot = cur;
+        }
+    }
+    KG_CHECK_HIP(hipEventRecord(s->ev_t2, st));
+    KG_CHECK_HIP(hipStreamSynchronize(st));
+    // the replay queued after the finishing one ran with the loop condition false: a no-op
+    const int* fin = slot[final_slot];
+    const int sidx = fin[KS_START];
+    result->n_tokens = sidx + 1;
+    result->new_tokens = sidx - T0 + 1;
+    result->rounds = fin[KS_ROUND];
+    result->drafted_total = fin[KS_NDRAFT_TOTAL];
+    result->stopped_on_eos = fin[KS_STOP];
+    hipEventElapsedTime(&result->prefill_ms, s->ev_t0, s->ev_t1);
+    hipEventElapsedTime(&result->decode_ms, s->ev_t1, s->ev_t2);
+    KG_CHECK_HIP(hipMemcpy(out_tokens_host, s->tokens, (size_t)(sidx + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    if (accept_log_host && mode == 0) {
+        int n = fin[KS_ROUND];
+        if (n > accept_log_capacity) n = accept_log_capacity;
+        if (n > 0) KG_CHECK_HIP(hipMemcpy(accept_log_host, s->state + KS_HDR, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// kernel-level entry points
+// ---------------------------------------------------------------------------------
+extern "C" int kg_linear(int dtype, const void* w_packed, int N, int K, const void* x, int n_rows,
+                         int prologue, const void* norm_w, float eps,
+                         int epilogue, const void* resid, void* out, int out_stride,
+                         void* scratch, int nblocks, int nwaves, void* stream) {
+    g_err.clear();
+    kg_init_once();
+    if (!w_packed || !x || !out || !scratch) return fail(-1, "null argument");
+    if (n_rows < 1 || n_rows > KG_MAX_ROWS) return fail(-1, "n_rows must be in [1, 16]");
+    if (epilogue != EPI_STORE && epilogue != EPI_RESID && epilogue != EPI_SILU_MUL) return fail(-1, "epilogue must be 0, 1 or 3");
+    if (prologue == PRO_RMSNORM && !norm_w) return fail(-1, "norm_w required");
+    if (epilogue == EPI_RESID && !resid) return fail(-1, "resid required");
+    hipStream_t st = (hipStream_t)stream;
+    KgDyn* dyn = (KgDyn*)scratch;
+    KG_TRY(kg_launch_set_dyn(dyn, 1, n_rows, 0, st));
+    KgLinArgs a = lin_base(dyn, w_packed, N, K, x, K);
+    a.norm_w = norm_w; a.eps = eps; a.out = out; a.out_stride = out_stride; a.resid = resid; a.resid_stride = out_stride;
+    int rc = kg_launch_linear(a, dtype, n_rows, prologue, epilogue, nblocks > 0 ? nblocks : g_ncu * 2, nwaves > 0 ? nwaves : 8, st);
+    if (rc == -3) return fail(-3, "rows x K exceed LDS");
+    if (rc) return fail(rc, "kg_launch_linear failed");
+    return 0;
+}
+
+extern "C" int kg_qkv_rope_append(int dtype, const void* wqkv_packed, int d, int n_heads, int n_kv_heads, int head_dim,
+                                  const void* x, int n_rows, int pos0, const void* norm_w, float eps,
+                                  const float* rope_cos, const float* rope_sin,
+                                  void* q_out, void* k_cache, void* v_cache, int t_max,
+                                  void* scratch, int nblocks, int nwaves, void* stream) {
+    g_err.clear();
+    kg_init_once();
+    if (!wqkv_packed || !x || !norm_w || !rope_cos || !rope_sin || !q_out || !k_cache || !v_cache || !scratch) return fail(-1, "null argument");
+    if (n_rows < 1 || n_rows > KG_MAX_ROWS || pos0 < 0 || pos0 + n_rows > t_max) return fail(-1, "bad rows / positions");
+    hipStream_t st = (hipStream_t)stream;
+    KgDyn* dyn = (KgDyn*)scratch;
+    KG_TRY(kg_launch_set_dyn(dyn, 1, n_rows, pos0, st));
+    const int qd = n_heads * head_dim, kvd = n_kv_heads * head_dim;
+    KgLinArgs a = lin_base(dyn, wqkv_packed, qd + 2 * kvd, d, x, d);
+    a.norm_w = norm_w; a.eps = eps; a.q_out = q_out; a.k_cache = k_cache; a.v_cache = v_cache;
+    a.rope_cos = rope_cos; a.rope_sin = rope_sin; a.head_dim = head_dim; a.q_dim = qd; a.kv_dim = kvd; a.t_max = t_max;
+    int rc = kg_launch_linear(a, dtype, n_rows, PRO_RMSNORM, EPI_ROPE_KV, nblocks > 0 ? nblocks : g_ncu * 2, nwaves > 0 ? nwaves : 8, st);
+    if (rc) return fail(rc, "kg_launch_linear failed");
+    return 0;
+}
+
+extern "C" size_t kg_attention_scratch_bytes(int n_heads, int head_dim, int nsplit) {
+    return 256 + (size_t)nsplit * KG_MAX_ROWS * n_heads * (head_dim + 2) * sizeof(float) + 512;
+}
+
+extern "C" int kg_attention(int dtype, const void* q, int n_rows, int pos0, const void* k_cache, const void* v_cache,
+                            int n_heads, int n_kv_heads, int head_dim, int t_max, int nsplit,
+                            void* out, void* scratch, void* stream) {
+    g_err.clear();
+    kg_init_once();
+    if (!q || !k_cache || !v_cache || !out || !scratch) return fail(-1, "null argument");
+    if (n_rows < 1 || n_rows > KG_MAX_ROWS || pos0 < 0 || pos0 + n_rows > t_max || nsplit < 1 || nsplit > 32) return fail(-1, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    KgDyn* dyn = (KgDyn*)scratch;
+    KG_TRY(kg_launch_set_dyn(dyn, 1, n_rows, pos0, st));
+    KgAttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dyn = dyn; a.q = q; a.k_cache = k_cache; a.v_cache = v_cache; a.H = n_heads; a.Hkv = n_kv_heads; a.hd = head_dim; a.t_max = t_max;
+    a.nsplit = nsplit; a.max_rows = n_rows;
+    a.part_o = (float*)((char*)scratch + 256);
+    a.part_ml = a.part_o + (size_t)nsplit * KG_MAX_ROWS * n_heads * head_dim;
+    // partial buffers are indexed with max_rows = n_rows, within the KG_MAX_ROWS-sized scratch
+    a.out = out;
+    int rc = kg_launch_attn(a, dtype, st);
+    if (rc) return fail(rc, "kg_launch_attn failed (head_dim must be 16/32/64/128)");
+    return 0;
+}
+
+extern "C" size_t kg_head_scratch_bytes(int vocab) {
+    return 256 + (size_t)KG_MAX_ROWS * ((vocab + 15) / 16) * 4 * sizeof(float);
+}
+
+extern "C" int kg_head(int dtype, const void* w_packed, int vocab, int d, const void* x, int n_rows,
+                       int prologue, const void* norm_w, float eps,
+                       void* logits_out, int* argmax_out, float* pmax_out,
+                       void* scratch, int nblocks, int nwaves, void* stream) {
+    g_err.clear();
+    kg_init_once();
+    if (!w_packed || !x || !scratch || !argmax_out || !pmax_out) return fail(-1, "null argument");
+    if (n_rows < 1 || n_rows > KG_MAX_ROWS) return fail(-1, "n_rows must be in [1, 16]");
+    if (prologue == PRO_RMSNORM && !norm_w) return fail(-1, "norm_w required");
+    hipStream_t st = (hipStream_t)stream;
+    KgDyn* dyn = (KgDyn*)scratch;
+    KG_TRY(kg_launch_set_dyn(dyn, 1, n_rows, 0, st));
+    KgLinArgs a = lin_base(dyn, w_packed, vocab, d, x, d);
+    a.norm_w = norm_w; a.eps = eps;
+    a.head_part = (float*)((char*)scratch + 256); a.head_part_stride = (vocab + 15) / 16;
+    a.logits_out = logits_out; a.logits_stride = vocab;
+    int nb = nblocks > 0 ? nblocks : g_ncu * 2;
+    const int G = (vocab + 15) / 16;
+    if (nb > G) nb = G;
+    int rc = kg_launch_linear(a, dtype, n_rows, prologue, EPI_HEAD, nb, nwaves > 0 ? nwaves : 8, st);
+    if (rc) return fail(rc, "kg_launch_linear failed");
+    KG_TRY(kg_launch_head_finalize(dyn, a.head_part, a.head_part_stride, nb, n_rows, argmax_out, pmax_out, st));
+    return 0;
+}

@@ -1,0 +1,103 @@
+// Shared device-side definitions for the Kangaroo decode kernels (gfx950 / CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KG_MAX_ROWS 16          // rows one M-row pass can carry (verify needs steps+1 <= 7)
+#define KG_TILE_ROWS 16         // weight rows per packed tile
+#define KG_TILE_K 32            // k elements per packed tile
+#define KG_TILE_ELEMS 512       // 16 x 32 elements = 1 KiB of 16-bit weights
+
+enum { KG_F16 = 0, KG_BF16 = 1 };
+
+// Per-pass dynamic parameters.  They live in device memory so that a captured graph
+// can be replayed while positions, row counts and the on/off switch change.
+struct KgDyn {
+    int active;                 // 0: every kernel of the pass returns at once
+    int n_rows;                 // valid rows (1..KG_MAX_ROWS)
+    int pos[KG_MAX_ROWS];       // position id == KV-cache slot of each row
+    int pad[14];
+};
+
+// Decode-loop state (one int32 array in device memory).  Indices:
+enum {
+    KS_START = 0,       // start_index s: tokens [0..s] are final
+    KS_END = 1,         // end_index e: next free token slot
+    KS_ADAPTER_LEN = 2, // adapter KV length
+    KS_STOP = 3,        // eos was produced
+    KS_ALIVE = 4,       // this round runs (loop condition held at round start)
+    KS_DRAFT_ON = 5,    // the next adapter/head step runs
+    KS_ROUND = 6,       // verify rounds finished
+    KS_CTX = 7,         // context length T0
+    KS_MAX_INFER = 8,   // min(max_length, T0 + max_new_tokens)
+    KS_STEPS = 9,       // SPECULATIVE_DECODING_STEPS
+    KS_EOS = 10,
+    KS_THRESH_LO = 11,  // threshold as a double: low / high 32 bits
+    KS_THRESH_HI = 17,
+    KS_SCORE = 12,      // float bits of the last draft confidence
+    KS_DRAFTED = 13,    // adapter steps taken this round
+    KS_Q_PREV = 14,     // rows of the previous verify pass
+    KS_VANILLA_POS = 15,// vanilla decode: position of the token being fed
+    KS_NDRAFT_TOTAL = 16,
+    KS_HDR = 32,        // accept log starts here: [KS_HDR + 2*r] = accept, [+1] = drafted
+};
+
+typedef _Float16 kg_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 kg_h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 kg_b2 __attribute__((ext_vector_type(2)));
+typedef __bf16 kg_b8 __attribute__((ext_vector_type(8)));
+typedef float kg_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int kg_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned short kg_us8 __attribute__((ext_vector_type(8)));
+
+template <int DT> struct KgT;
+template <> struct KgT<KG_F16> {
+    static __device__ __forceinline__ float to_f(unsigned short u) {
+        _Float16 h = __builtin_bit_cast(_Float16, u);
+        return (float)h;
+    }
+    static __device__ __forceinline__ unsigned short from_f(float f) {
+        _Float16 h = (_Float16)f;
+        return __builtin_bit_cast(unsigned short, h);
+    }
+    static __device__ __forceinline__ float dot2(unsigned int a, unsigned int b, float c) {
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(kg_h2, a), __builtin_bit_cast(kg_h2, b), c, false);
+    }
+    static __device__ __forceinline__ kg_f4 mfma(kg_u4 a, kg_u4 b, kg_f4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(kg_h8, a), __builtin_bit_cast(kg_h8, b), c, 0, 0, 0);
+    }
+};
+template <> struct KgT<KG_BF16> {
+    static __device__ __forceinline__ float to_f(unsigned short u) {
+        return __builtin_bit_cast(float, ((unsigned int)u) << 16);
+    }
+    static __device__ __forceinline__ unsigned short from_f(float f) {
+        __bf16 h = (__bf16)f;   // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+        return __builtin_bit_cast(unsigned short, h);
+    }
+    static __device__ __forceinline__ float dot2(unsigned int a, unsigned int b, float c) {
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(kg_b2, a), __builtin_bit_cast(kg_b2, b), c, false);
+    }
+    static __device__ __forceinline__ kg_f4 mfma(kg_u4 a, kg_u4 b, kg_f4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kg_b8, a), __builtin_bit_cast(kg_b8, b), c, 0, 0, 0);
+    }
+};
+
+// round an fp32 value to the storage type and back (the reference's per-op store)
+template <int DT> __device__ __forceinline__ float kg_round(float f) { return KgT<DT>::to_f(KgT<DT>::from_f(f)); }
+
+__device__ __forceinline__ float kg_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float kg_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// streamed-once weight load: 16 B per lane, non-temporal
+__device__ __forceinline__ kg_u4 kg_ldg_stream(const kg_u4* p) { return __builtin_nontemporal_load(p); }
+
+#define KG_CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { kg_set_error(#x, e_); return -2; } } while (0)

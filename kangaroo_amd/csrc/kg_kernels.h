@@ -1,0 +1,72 @@
+// Host-visible kernel launchers (internal to the shared library).
+#pragma once
+#include "kg_common.h"
+
+enum { PRO_NONE = 0, PRO_RMSNORM = 1 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_ROPE_KV = 2, EPI_SILU_MUL = 3, EPI_HEAD = 4 };
+
+struct KgLinArgs {
+    const void* W;              // packed weights, ceil16(N) x K
+    int N, K;
+    const KgDyn* dyn;
+    // input rows [n_rows, K], element stride x_stride
+    const void* x; int x_stride;
+    int x_last_row;             // VEC mode: read row dyn->n_rows-1 of x instead of row 0
+    const void* norm_w; float eps;          // PRO_RMSNORM
+    // EPI_STORE / EPI_RESID / EPI_SILU_MUL
+    void* out; int out_stride;
+    const void* resid; int resid_stride;
+    // EPI_ROPE_KV
+    void* q_out; void* k_cache; void* v_cache;
+    const float* rope_cos; const float* rope_sin;   // [max_pos, head_dim/2]
+    int head_dim, q_dim, kv_dim, t_max;
+    // EPI_HEAD
+    float* head_part; int head_part_stride;         // [rows][head_part_stride][4]
+    void* logits_out; int logits_stride;            // optional
+};
+
+size_t kg_linear_smem(int mfma, int max_rows, int K, int nwaves);
+int kg_launch_linear(const KgLinArgs& a, int dtype, int max_rows, int pro, int epi, int nblocks, int nwaves, hipStream_t st);
+void kg_linear_init();
+
+struct KgAttnArgs {
+    const KgDyn* dyn;
+    const void* q;              // [n_rows, H*hd]
+    const void* k_cache;        // [Hkv, t_max, hd]
+    const void* v_cache;
+    int H, Hkv, hd, t_max;
+    int nsplit;
+    float* part_o;              // [nsplit][rows][H][hd]
+    float* part_ml;             // [nsplit][rows][H][2]
+    void* out;                  // [n_rows, H*hd]
+    int max_rows;
+};
+int kg_launch_attn(const KgAttnArgs& a, int dtype, hipStream_t st);
+
+// small control / glue kernels
+int kg_launch_set_dyn(KgDyn* dyn, int active, int n_rows, int pos0, hipStream_t st);
+int kg_launch_embed(const KgDyn* dyn, const int* tokens, const void* embed, int d, void* out, int out_stride, hipStream_t st);
+int kg_launch_rmsnorm(const KgDyn* dyn, const void* x, int x_stride, const void* w, float eps, int K, void* out, int out_stride, int dtype, hipStream_t st);
+int kg_launch_head_finalize(const KgDyn* dyn, const float* head_part, int head_part_stride, int nblocks, int max_rows,
+                            int* tok_out, float* pmax_out, hipStream_t st);
+
+struct KgLoopBufs {
+    int* state;                 // KS_* layout
+    int* tokens;                // [max_length]
+    KgDyn* dyn_shallow; KgDyn* dyn_adapter; KgDyn* dyn_verify;
+    void* exited;               // [steps+1][d]
+    void* prev_exit;            // [d]
+    void* adapter_in;           // [2][d]
+    int* head_tok;              // [KG_MAX_ROWS] argmax per row of the last head pass
+    float* head_pmax;           // [KG_MAX_ROWS]
+    int d; int elt;
+};
+int kg_launch_round_begin(const KgLoopBufs& b, hipStream_t st);
+int kg_launch_step_mid(const KgLoopBufs& b, int step, hipStream_t st);        // after the shallow pass: adapter rows
+int kg_launch_step_end(const KgLoopBufs& b, int step, const float* head_part, int nblocks, hipStream_t st);  // after the draft head
+int kg_launch_verify_begin(const KgLoopBufs& b, hipStream_t st);
+int kg_launch_accept(const KgLoopBufs& b, const float* head_part, int stride, int nblocks, hipStream_t st);
+int kg_launch_vanilla_begin(const KgLoopBufs& b, hipStream_t st);
+int kg_launch_vanilla_end(const KgLoopBufs& b, const float* head_part, int nblocks, hipStream_t st);
+
+void kg_set_error(const char* what, hipError_t e);

@@ -1,0 +1,224 @@
+"""Device engine: packs weights, owns the HBM-resident buffers (PyTorch allocates them)
+and calls libkangaroo_hip.so through its C ABI.
+
+Everything the decode path touches stays resident on the GPU: packed weights, the
+in-place KV caches [layers, Hkv, t_max, hd] of the base model and the adapter, and one
+workspace for activations, loop state and the token buffer.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .config import LlamaShape
+from .packing import pack_weight, pack_qkv, pack_gate_up, rope_tables
+
+
+def _dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float16:
+        return _lib.DT_F16
+    if dtype == torch.bfloat16:
+        return _lib.DT_BF16
+    raise ValueError(f"the HIP decode path stores weights in float16 or bfloat16, not {dtype}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@dataclass
+class GenStats:
+    n_tokens: int
+    new_tokens: int
+    rounds: int
+    drafted_total: int
+    stopped_on_eos: bool
+    prefill_ms: float
+    decode_ms: float
+    accept_lengths: List[int]
+    draft_lengths: List[int]
+
+
+class KangarooEngine:
+    """Packed weights + caches + session for one (base model, adapter) pair on one GPU."""
+
+    def __init__(self, shape: LlamaShape, base_sd: Dict[str, torch.Tensor], adapter_sd: Dict[str, torch.Tensor],
+                 exit_layer: int = 2, dtype: torch.dtype = torch.float16, device="cuda", max_length: int = 2048,
+                 release_source: bool = False):
+        if not torch.cuda.is_available():
+            raise _lib.KangarooHipError("no GPU visible: the Kangaroo decode path has no CPU fallback")
+        self.lib = _lib.lib()
+        self.shape = shape
+        self.exit_layer = exit_layer
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.max_length = max_length
+        self._handle = C.c_void_p(0)
+        dev = self.device
+
+        def get(sd, k):
+            t = sd[k]
+            if release_source:
+                sd[k] = None
+            return t.to(device=dev, dtype=dtype)
+
+        H, Hkv, hd = shape.num_attention_heads, shape.num_key_value_heads, shape.head_dim
+        self._keep: List[torch.Tensor] = []     # every tensor whose address the session holds
+
+        def keep(t):
+            self._keep.append(t)
+            return t
+
+        layers = (_lib.KgLayerWeights * shape.num_hidden_layers)()
+        for i in range(shape.num_hidden_layers):
+            p = f"model.layers.{i}."
+            lw = layers[i]
+            lw.wqkv = keep(pack_qkv(get(base_sd, p + "self_attn.q_proj.weight"), get(base_sd, p + "self_attn.k_proj.weight"),
+                                    get(base_sd, p + "self_attn.v_proj.weight"), H, Hkv, hd)).data_ptr()
+            lw.wo = keep(pack_weight(get(base_sd, p + "self_attn.o_proj.weight"))).data_ptr()
+            lw.wgu = keep(pack_gate_up(get(base_sd, p + "mlp.gate_proj.weight"), get(base_sd, p + "mlp.up_proj.weight"))).data_ptr()
+            lw.wdown = keep(pack_weight(get(base_sd, p + "mlp.down_proj.weight"))).data_ptr()
+            lw.norm1 = keep(get(base_sd, p + "input_layernorm.weight").contiguous()).data_ptr()
+            lw.norm2 = keep(get(base_sd, p + "post_attention_layernorm.weight").contiguous()).data_ptr()
+        self._layers = layers
+        w = _lib.KgWeights()
+        self.embed = keep(get(base_sd, "model.embed_tokens.weight").contiguous())
+        w.embed = self.embed.data_ptr()
+        w.final_norm = keep(get(base_sd, "model.norm.weight").contiguous()).data_ptr()
+        w.lm_head = keep(pack_weight(get(base_sd, "lm_head.weight"))).data_ptr()
+        w.layers = layers
+        a = "layers.0."
+        w.adapter.wqkv = keep(pack_qkv(get(adapter_sd, a + "self_attn.q_proj.weight"), get(adapter_sd, a + "self_attn.k_proj.weight"),
+                                       get(adapter_sd, a + "self_attn.v_proj.weight"), H, Hkv, hd)).data_ptr()
+        w.adapter.wo = keep(pack_weight(get(adapter_sd, a + "self_attn.o_proj.weight"))).data_ptr()
+        w.adapter.wgu = None
+        w.adapter.wdown = None
+        w.adapter.norm1 = keep(get(adapter_sd, a + "input_layernorm.weight").contiguous()).data_ptr()
+        w.adapter.norm2 = None
+        w.adapter_norm = keep(get(adapter_sd, "norm.weight").contiguous()).data_ptr()
+        cos, sin = rope_tables(hd, shape.max_position_embeddings, shape.rope_base, device=dev)
+        w.rope_cos = keep(cos).data_ptr()
+        w.rope_sin = keep(sin).data_ptr()
+        self._weights = w
+
+        ks = _lib.KgShape(_dtype_code(dtype), shape.hidden_size, shape.num_hidden_layers, H, Hkv, hd,
+                          shape.intermediate_size, shape.vocab_size, shape.rms_norm_eps,
+                          shape.max_position_embeddings, exit_layer)
+        self._kshape = ks
+        t_max = max_length
+        self.k_cache = torch.zeros((shape.num_hidden_layers, Hkv, t_max, hd), dtype=dtype, device=dev)
+        self.v_cache = torch.zeros_like(self.k_cache)
+        self.ak_cache = torch.zeros((Hkv, t_max, hd), dtype=dtype, device=dev)
+        self.av_cache = torch.zeros_like(self.ak_cache)
+        wbytes = self.lib.kg_workspace_bytes(C.byref(ks), t_max)
+        self.workspace = torch.zeros(wbytes, dtype=torch.uint8, device=dev)
+        b = _lib.KgBuffers(self.k_cache.data_ptr(), self.v_cache.data_ptr(), self.ak_cache.data_ptr(), self.av_cache.data_ptr(),
+                           self.workspace.data_ptr(), wbytes, t_max)
+        self._buffers = b
+        h = C.c_void_p(0)
+        _lib.check(self.lib.kg_session_create(C.byref(ks), C.byref(w), C.byref(b), C.byref(h)), "kg_session_create")
+        self._handle = h
+        self.tokens = self._region("tokens", t_max * 4).view(torch.int32)
+        self.hs_early = self._region("hs_early", t_max * shape.hidden_size * 2).view(dtype).view(t_max, shape.hidden_size)
+
+    # ------------------------------------------------------------------
+    def _region(self, name: str, nbytes: int) -> torch.Tensor:
+        p = self.lib.kg_session_ptr(self._handle, name.encode())
+        if not p:
+            raise _lib.KangarooHipError(f"unknown workspace region {name}")
+        off = p - self.workspace.data_ptr()
+        return self.workspace[off:off + nbytes]
+
+    def close(self):
+        if self._handle:
+            self.lib.kg_session_destroy(self._handle)
+            self._handle = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_tuning(self, **kw):
+        for k, v in kw.items():
+            _lib.check(self.lib.kg_session_set(self._handle, k.encode(), int(v)), f"kg_session_set({k})")
+
+    def weight_bytes(self) -> Dict[str, int]:
+        s = self.shape
+        return {"layer": s.layer_weight_bytes(), "adapter": s.attn_only_weight_bytes(), "head": s.head_weight_bytes(),
+                "kv_per_pos_layer": s.kv_bytes_per_position()}
+
+    # ---- passes (reference-interface mirror classes call these) -------------------
+    def forward_layers(self, layer_begin: int, layer_end: int, x_in: Optional[torch.Tensor], pos0: int, n_rows: int) -> torch.Tensor:
+        out = torch.empty((n_rows, self.shape.hidden_size), dtype=self.dtype, device=self.device)
+        if x_in is not None:
+            x_in = x_in.reshape(n_rows, self.shape.hidden_size).to(self.dtype).contiguous()
+        _lib.check(self.lib.kg_forward_layers(self._handle, layer_begin, layer_end, _ptr(x_in), pos0, n_rows, _ptr(out), _stream()),
+                   "kg_forward_layers")
+        return out
+
+    def final_norm(self, x: torch.Tensor) -> torch.Tensor:
+        n = x.shape[0]
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        _lib.check(self.lib.kg_final_norm(self._handle, _ptr(x), n, _ptr(out), _stream()), "kg_final_norm")
+        return out
+
+    def adapter_forward(self, x_in: torch.Tensor, pos0: int, n_rows: int) -> torch.Tensor:
+        x_in = x_in.reshape(n_rows, self.shape.hidden_size).to(self.dtype).contiguous()
+        out = torch.empty_like(x_in)
+        _lib.check(self.lib.kg_adapter_forward(self._handle, _ptr(x_in), pos0, n_rows, _ptr(out), _stream()), "kg_adapter_forward")
+        return out
+
+    def head_logits(self, x: torch.Tensor, want_stats: bool = False):
+        n = x.shape[0]
+        x = x.to(self.dtype).contiguous()
+        logits = torch.empty((n, self.shape.vocab_size), dtype=self.dtype, device=self.device)
+        if want_stats:
+            am = torch.empty(n, dtype=torch.int32, device=self.device)
+            pm = torch.empty(n, dtype=torch.float32, device=self.device)
+            _lib.check(self.lib.kg_head_logits(self._handle, _ptr(x), n, _ptr(logits), _ptr(am), _ptr(pm), _stream()), "kg_head_logits")
+            return logits, am, pm
+        _lib.check(self.lib.kg_head_logits(self._handle, _ptr(x), n, _ptr(logits), None, None, _stream()), "kg_head_logits")
+        return logits
+
+    def set_tokens(self, ids: torch.Tensor, pos0: int):
+        ids = ids.reshape(-1)
+        self.tokens[pos0:pos0 + ids.numel()] = ids.to(device=self.device, dtype=torch.int32)
+
+    # ---- fused loops ---------------------------------------------------------------
+    def generate(self, prompt_ids, max_new_tokens: int, mode: str = "kangaroo", steps: int = 6, threshold: float = 0.6,
+                 eos_token_id: int = 2, max_length: Optional[int] = None):
+        """Whole kangaroo_forward (mode='kangaroo') or plain greedy decoding (mode='vanilla')
+        on the device.  Returns (output_ids list, GenStats)."""
+        if isinstance(prompt_ids, torch.Tensor):
+            prompt = prompt_ids.reshape(-1).to("cpu", torch.int32).contiguous()
+        else:
+            prompt = torch.tensor(list(prompt_ids), dtype=torch.int32)
+        T0 = prompt.numel()
+        max_length = max_length or self.max_length
+        out = torch.empty(max_length + 8, dtype=torch.int32)
+        cap = max_length + 8
+        log = torch.zeros(2 * cap, dtype=torch.int32)
+        res = _lib.KgGenResult()
+        i32p = C.POINTER(C.c_int32)
+        rc = self.lib.kg_generate(self._handle, 0 if mode == "kangaroo" else 1,
+                                  C.cast(prompt.data_ptr(), i32p), T0, max_new_tokens, max_length, steps, float(threshold),
+                                  eos_token_id, C.cast(out.data_ptr(), i32p), C.cast(log.data_ptr(), i32p), cap,
+                                  C.byref(res), _stream())
+        _lib.check(rc, "kg_generate")
+        ids = out[:res.n_tokens].tolist()
+        rounds = res.rounds if mode == "kangaroo" else 0
+        acc = log[0:2 * rounds:2].tolist()
+        drafted = log[1:2 * rounds:2].tolist()
+        return ids, GenStats(res.n_tokens, res.new_tokens, res.rounds, res.drafted_total, bool(res.stopped_on_eos),
+                             res.prefill_ms, res.decode_ms, acc, drafted)

@@ -1,0 +1,186 @@
+"""End-to-end parity (GPU): the HIP path through the C ABI against
+ (a) the committed golden vectors written by the reference's own code, and
+ (b) the CPU oracle run live on the same seeded weights at sizes it finishes in seconds.
+
+Bar: output ids, accept lengths and per-round draft lengths bit-exact; logits within
+1e-2 of the row's max-abs.  Where a sequence diverges, the divergence must be an argmax
+near-tie: `explain_divergence` re-scores the device's sequence with the oracle
+(teacher forcing) and requires the device's token to be within tolerance of the
+oracle's best logit at the first differing position."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from kangaroo_amd.config import get_shape
+from kangaroo_amd.inference import kangaroo_forward, kangaroo_forward_stepwise, vanilla_forward
+from kangaroo_amd.kangaroo_model import KangarooModel
+from kangaroo_amd.weights import Recipe, synth_state_dicts
+from oracle import kangaroo_oracle as ko
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "*.npz")) if not p.endswith("layers.npz"))
+LOGIT_TOL = 1e-2
+
+
+def load_case(path):
+    z = np.load(path, allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    base = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("base/")}
+    adapter = {k[8:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("adapter/")}
+    return z, meta, base, adapter
+
+
+def oracle_model(shape_name, base, adapter, L, round_to=None):
+    return ko.OracleKangarooModel(ko.Shape(**get_shape(shape_name).to_dict()), base, adapter, L, round_to)
+
+
+def explain_divergence(dev_ids, ref_ids, T0, omodel):
+    """First differing position must be a near-tie for the oracle under teacher forcing."""
+    n = min(len(dev_ids), len(ref_ids))
+    first = next((i for i in range(n) if dev_ids[i] != ref_ids[i]), None)
+    if first is None:
+        return None
+    assert first >= T0
+    out = omodel.base_model(torch.tensor([dev_ids[:first]]))
+    row = out.logits[0, -1]
+    best = float(row.max())
+    gap = best - float(row[dev_ids[first]])
+    scale = float(row.abs().max())
+    assert gap <= LOGIT_TOL * scale, f"divergence at {first} is not a near-tie: gap {gap} vs scale {scale}"
+    return first
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_fused_loop_matches_reference_golden(path):
+    z, meta, base, adapter = load_case(path)
+    shape = get_shape(meta["shape"])
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, meta["exit_layer"])
+    for pi in range(meta["n_prompts"]):
+        ids = torch.from_numpy(z[f"p{pi}/input_ids"]).cuda()
+        out, new_tok, idx, accept, st = kangaroo_forward(ids, model, meta["eos"], meta["max_new_tokens"], EARLY_STOP_LAYER=meta["exit_layer"],
+                                                         SPECULATIVE_DECODING_STEPS=meta["steps"], threshold=meta["threshold"], return_stats=True)
+        gold = z[f"p{pi}/output_ids"].tolist()
+        if out[0] != gold:
+            om = oracle_model(meta["shape"], base, adapter, meta["exit_layer"])
+            explain_divergence(out[0], gold, ids.shape[1], om)
+            pytest.xfail("argmax near-tie (explained)")
+        assert new_tok == int(z[f"p{pi}/new_token"])
+        assert idx == int(z[f"p{pi}/idx"])
+        assert accept == z[f"p{pi}/accept_length_list"].tolist()
+        assert st.draft_lengths == z[f"p{pi}/draft_lengths"].tolist()
+        # lossless: plain greedy decoding on the same kernels gives the same ids
+        van = vanilla_forward(ids, model, meta["eos"], new_tok)[0][0]
+        assert van == out[0][:len(van)]
+        assert len(van) == len(out[0]) or van[-1] == meta["eos"]
+
+
+@pytest.mark.parametrize("path", CASES[:3], ids=[os.path.basename(p)[:-4] for p in CASES[:3]])
+def test_stepwise_interface_matches_golden(path):
+    """The reference-shaped methods (forward_draft_or_large_model / forward_early_stop /
+    head_model with view-based caches) driven pass by pass."""
+    z, meta, base, adapter = load_case(path)
+    shape = get_shape(meta["shape"])
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, meta["exit_layer"])
+    for pi in range(meta["n_prompts"]):
+        ids = torch.from_numpy(z[f"p{pi}/input_ids"]).cuda()
+        tr = {}
+        out, new_tok, idx, accept = kangaroo_forward_stepwise(ids, model, meta["eos"], meta["max_new_tokens"], EARLY_STOP_LAYER=meta["exit_layer"],
+                                                              SPECULATIVE_DECODING_STEPS=meta["steps"], threshold=meta["threshold"], trace=tr)
+        gold = z[f"p{pi}/output_ids"].tolist()
+        if out[0] != gold:
+            explain_divergence(out[0], gold, ids.shape[1], oracle_model(meta["shape"], base, adapter, meta["exit_layer"]))
+            pytest.xfail("argmax near-tie (explained)")
+        assert accept == z[f"p{pi}/accept_length_list"].tolist()
+        assert tr["draft_lengths"] == z[f"p{pi}/draft_lengths"].tolist()
+        np.testing.assert_allclose(np.asarray(tr.get("p_max", [])), z[f"p{pi}/p_max"], atol=2e-2)
+
+
+def test_logits_against_golden():
+    """Prefill + draft + verify logits of the device path vs the reference's."""
+    z, meta, base, adapter = load_case(CASES[1])
+    shape = get_shape(meta["shape"])
+    L = meta["exit_layer"]
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, L)
+    om = oracle_model(meta["shape"], base, adapter, L)
+    ids = torch.from_numpy(z["p0/input_ids"])
+    o_ref = om.base_model(ids)
+    o_dev = model.base_model(ids.cuda())
+    scale = float(o_ref.logits.abs().max())
+    assert float((o_dev.logits.float().cpu() - o_ref.logits).abs().max()) <= LOGIT_TOL * scale
+    h_ref, h_dev = o_ref.hidden_states[L], o_dev.hidden_states[L].float().cpu()
+    assert float((h_dev - h_ref).abs().max()) <= LOGIT_TOL * float(h_ref.abs().max())
+    # adapter prefill + one incremental step
+    a_ref, kv_ref = om.adapter_model.forward_early_stop(inputs_embeds=o_ref.hidden_states[L])
+    a_dev, kv_dev = model.adapter_model.forward_early_stop(inputs_embeds=o_dev.hidden_states[L], use_cache=True)
+    assert float((a_dev.float().cpu() - a_ref).abs().max()) <= LOGIT_TOL * float(a_ref.abs().max())
+    assert kv_dev[0][0].shape == kv_ref[0][0].shape
+    assert float((kv_dev[0][0].float().cpu() - kv_ref[0][0]).abs().max()) <= LOGIT_TOL * float(kv_ref[0][0].abs().max())
+
+
+@pytest.mark.parametrize("shape_name,L,recipe,seed", [
+    ("small", 2, Recipe.agreeable(0.3, 8.0), 11),
+    ("small", 3, Recipe(), 12),
+    ("tinyllama-1.1b", 2, Recipe.agreeable(0.2, 10.0), 13),
+])
+def test_against_live_oracle(shape_name, L, recipe, seed):
+    """Larger shapes than the fixtures: oracle (fp32 CPU) and device on the same weights."""
+    shape = get_shape(shape_name)
+    if shape_name == "tinyllama-1.1b":
+        shape = type(shape)(**{**shape.to_dict(), "num_hidden_layers": 4})     # same layer shape, 4 layers: seconds on the CPU
+    base, adapter = synth_state_dicts(shape, L, seed=seed, dtype=torch.float16, recipe=recipe)
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, L)
+    om = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), base, adapter, L)
+    g = torch.Generator().manual_seed(seed)
+    for plen in (9, 40):
+        ids = torch.randint(3, shape.vocab_size, (1, plen), generator=g)
+        tr = ko.Trace()
+        ref = ko.kangaroo_forward(ids, om, 2, 48, EARLY_STOP_LAYER=L, trace=tr)
+        out, new_tok, idx, accept, st = kangaroo_forward(ids.cuda(), model, 2, 48, EARLY_STOP_LAYER=L, return_stats=True)
+        if out[0] != ref[0][0]:
+            om2 = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), base, adapter, L)
+            explain_divergence(out[0], ref[0][0], plen, om2)
+            continue
+        assert (new_tok, idx, accept) == (ref[1], ref[2], ref[3])
+        assert st.draft_lengths == tr.draft_lengths
+        van = vanilla_forward(ids.cuda(), model, 2, new_tok)[0][0]
+        assert van == out[0][:len(van)]
+
+
+def test_bf16_runs_and_is_lossless():
+    shape = get_shape("small")
+    base, adapter = synth_state_dicts(shape, 2, seed=21, dtype=torch.bfloat16, recipe=Recipe.agreeable(0.3, 8.0))
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.bfloat16, 2)
+    ids = torch.randint(3, shape.vocab_size, (1, 17), generator=torch.Generator().manual_seed(3)).cuda()
+    out, new_tok, idx, accept = kangaroo_forward(ids, model, 2, 64)
+    van = vanilla_forward(ids, model, 2, new_tok)[0][0]
+    om = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), base, adapter, 2)
+    if van != out[0][:len(van)]:
+        explain_divergence(out[0], van, 17, om)
+    assert max(accept) <= 7 and min(accept) >= 1 and sum(accept[1:]) == new_tok - 1
+
+
+def test_error_conventions_and_bounds():
+    z, meta, base, adapter = load_case(CASES[0])
+    shape = get_shape(meta["shape"])
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, 2)
+    with pytest.raises(AssertionError):
+        model.base_model.forward_draft_or_large_model(in_tokens_small=torch.tensor([[3]]).cuda())
+    model.base_model.past_key_values = []
+    with pytest.raises(ValueError):
+        model.base_model.forward_draft_or_large_model()
+    with pytest.raises(ValueError):
+        model.base_model.forward_draft_or_large_model(in_tokens_small=torch.tensor([[3]]).cuda(), in_features_large=torch.zeros(1, 1, 64).cuda())
+    with pytest.raises(NotImplementedError):
+        model.forward()
+    # the loop stops 1 + steps short of the budget (inference_kangaroo.py:46)
+    ids = torch.from_numpy(z["p0/input_ids"]).cuda()
+    out, new_tok, idx, accept = kangaroo_forward(ids, model, -1, 40)
+    assert new_tok <= 40 and new_tok >= 40 - 1 - 6
+    out1, new1, _, acc1 = kangaroo_forward(ids, model, -1, 1)            # no round fits: only the prefill token
+    assert new1 == 1 and acc1 == [1] and len(out1[0]) == ids.shape[1] + 1
