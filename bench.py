@@ -1,0 +1,207 @@
+"""Benchmark of the Kangaroo decode path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one whole kangaroo_forward call (prefill + draft/verify rounds) on one
+synthetic Spec-Bench-shaped prompt.  At N=1 the workload is BASELINE.json's
+configs[1]: Vicuna-7B shape, fp16, exitlayer=2, steps=6, threshold=0.6, greedy,
+max_new_tokens=1024, random-init weights with a recipe calibrated so the mean accept
+length is near the reference's recorded 2.05.  For N>1 (launched by
+torch.distributed.run, one rank per GPU) every rank holds a full replica and decodes
+its own K prompts: independent bsz=1 streams, no data-path collective ("weak" scaling).
+
+Rank 0 prints ONE JSON line: whole-job decode tokens/s (prefill inside the timed
+region, as the reference's harness times it), speed-up over plain greedy decoding on
+the same kernels, achieved weight-streaming GB/s, the roofline record of the dominant
+kernel (timed live with HIP events on its launch stream) and, at N=1, the CPU
+baseline: the oracle's restatement of the reference loop on the host cores over a
+bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from kangaroo_amd.config import get_shape, DEFAULT_EXIT_LAYER
+from kangaroo_amd.harness import spec_bench_prompts
+from kangaroo_amd.kangaroo_model import KangarooModel
+from kangaroo_amd.weights import Recipe, synth_state_dicts
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+CAL_RECIPE = (0.08, 10.0)      # (deep_scale, head_scale): mean accept ~2 at the 7B shape
+
+
+def round_bytes(shape, L, d):
+    """Algorithmic weight bytes of one verify round with d drafted tokens (fp16):
+    (d+1) shallow passes + d (adapter + head) + verify of the remaining layers + head."""
+    lay, ad, hd = shape.layer_weight_bytes(), shape.attn_only_weight_bytes(), shape.head_weight_bytes()
+    return (d + 1) * L * lay + d * (ad + hd) + (shape.num_hidden_layers - L) * lay + hd
+
+
+def cpu_baseline(shape, L, base_sd_gpu, adapter_sd_gpu, steps, thr, budget_new=32, prompt_len=32):
+    """The oracle (CPU restatement of the reference loop, fp32 math on the same fp16
+    weights) timed on the host cores over one short prompt."""
+    from oracle import kangaroo_oracle as ko
+    t0 = time.time()
+    base = {k: v.to("cpu") for k, v in base_sd_gpu.items()}
+    adapter = {k: v.to("cpu") for k, v in adapter_sd_gpu.items()}
+    om = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), base, adapter, L)
+    del base, adapter
+    setup = time.time() - t0
+    ids = torch.randint(3, shape.vocab_size, (1, prompt_len), generator=torch.Generator().manual_seed(7))
+    t0 = time.time()
+    out, new_tok, idx, accept = ko.kangaroo_forward(ids, om, -1, budget_new, EARLY_STOP_LAYER=L,
+                                                    SPECULATIVE_DECODING_STEPS=steps, threshold=thr)
+    dt = time.time() - t0
+    return {"value": new_tok / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 prompt of {prompt_len} tokens, {new_tok} new tokens in {dt:.1f} s (prefill included), fp32 math; "
+                      f"weights upcast in {setup:.0f} s (untimed)",
+            "mean_accept": sum(accept) / len(accept)}, out[0], ids
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6, help="prompts decoded per rank inside the timed region")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="vicuna-7b")
+    ap.add_argument("--max-new-tokens", type=int, default=1024)
+    ap.add_argument("--spec-steps", type=int, default=6)
+    ap.add_argument("--threshold", type=float, default=0.6)
+    ap.add_argument("--recipe", default=f"{CAL_RECIPE[0]}:{CAL_RECIPE[1]}")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vanilla", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    shape = get_shape(a.model)
+    L = DEFAULT_EXIT_LAYER.get(a.model, 2)
+    ds, hs = [float(x) for x in a.recipe.split(":")]
+    base_sd, adapter_sd = synth_state_dicts(shape, L, seed=0, dtype=torch.float16, recipe=Recipe.agreeable(ds, hs), device=dev)
+    model = KangarooModel.from_state_dicts(shape, base_sd, adapter_sd, torch.float16, L, device=dev)
+    eng = model.engine
+
+    K, W = a.steps, a.warmup
+    allp = spec_bench_prompts(shape.vocab_size, (K + W) * world)
+    mine = allp[rank * (K + W):(rank + 1) * (K + W)]     # contiguous shard per rank
+    warm, timed = mine[:W], mine[W:]
+    eos = -1                                              # random weights have no meaningful eos: decode the full budget
+    kw = dict(steps=a.spec_steps, threshold=a.threshold, eos_token_id=eos)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for p in warm:
+        eng.generate(p.input_ids[0], a.max_new_tokens, mode="kangaroo", **kw)
+    if not warm:
+        eng.generate(timed[0].input_ids[0], 16, mode="kangaroo", **kw)       # graph capture outside the timed region
+    barrier()
+    t0 = time.time()
+    stats, outs = [], []
+    for p in timed:
+        out, st = eng.generate(p.input_ids[0], a.max_new_tokens, mode="kangaroo", **kw)
+        stats.append(st)
+        outs.append(out)
+    barrier()
+    elapsed = time.time() - t0
+    new_tokens = sum(s.new_tokens for s in stats)
+    tot = torch.tensor([float(new_tokens), elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = tot.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        total_tokens, t_job = float(tot[0]), float(tmax[1])
+    else:
+        total_tokens, t_job = float(tot[0]), elapsed
+
+    # ---- own vanilla decode on the same kernels, same prompts (not inside the timed region) ----
+    van_tps = speedup = None
+    lossless = None
+    if not a.no_vanilla:
+        eng.generate(timed[0].input_ids[0], 16, mode="vanilla", eos_token_id=eos)
+        torch.cuda.synchronize()
+        tv0 = time.time()
+        vtok = 0
+        agree = 0
+        for p, st, out in zip(timed, stats, outs):
+            vout, vst = eng.generate(p.input_ids[0], st.new_tokens, mode="vanilla", eos_token_id=eos)
+            vtok += vst.new_tokens
+            agree += int(vout == out)
+        torch.cuda.synchronize()
+        van_tps = vtok / (time.time() - tv0)
+        speedup = (new_tokens / elapsed) / van_tps
+        lossless = f"{agree}/{len(timed)} prompts token-identical to vanilla greedy"
+
+    # ---- achieved bytes / roofline ----
+    dec_ms = sum(s.decode_ms for s in stats)
+    bytes_dec = sum(round_bytes(shape, L, d) for s in stats for d in s.draft_lengths)
+    path_gbs = bytes_dec / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
+    rows = a.spec_steps + 1
+    us, wbytes = eng.bench_op("gateup", rows, iters=4 * shape.num_hidden_layers)
+    ach = wbytes / (us * 1e-6) / 1e9
+    roofline = {"bound": "hbm", "kernel": "kg_linear_kernel<f16, MFMA, RMSNorm, SiLU*mul> (gate/up projection of the verify pass)",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "us_per_launch": us, "algorithmic_bytes_per_launch": wbytes}
+    per_kernel = {}
+    for op in ("qkv", "o", "gateup", "down", "head"):
+        for r in (1, rows):
+            u, b = eng.bench_op(op, r, iters=2 * shape.num_hidden_layers)
+            per_kernel[f"{op}_rows{r}"] = {"us": round(u, 2), "GB/s": round(b / (u * 1e-6) / 1e9, 1)}
+
+    acc_all = [x for s in stats for x in ([1] + s.accept_lengths)]
+    d_all = [x for s in stats for x in s.draft_lengths]
+    res = {
+        "metric": "decode tokens/s at bsz=1 (Kangaroo, prefill included)", "value": total_tokens / t_job, "unit": "tokens/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * t_job / max(1, K), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"{a.model} shape fp16 Kangaroo exitlayer={L} steps={a.spec_steps} thr={a.threshold} greedy, "
+                               f"Spec-Bench-shaped synthetic prompts, max_new_tokens={a.max_new_tokens}, random-init weights "
+                               f"(deep_scale={ds}, head_scale={hs})",
+                   "prompts_per_gpu": K, "parallelism": f"prompt-sharded x{world} (replicas, no collectives)"},
+        "mean_accept": sum(acc_all) / max(1, len(acc_all)), "mean_draft": sum(d_all) / max(1, len(d_all)),
+        "decode_only_tokens_per_s_rank0": (new_tokens - len(stats)) / (dec_ms * 1e-3) if dec_ms > 0 else None,
+        "vanilla_tokens_per_s_rank0": van_tps, "speedup_vs_vanilla": speedup, "lossless": lossless,
+        "hbm_GBps_decode_loop_rank0": path_gbs, "hbm_frac_decode_loop": path_gbs / HBM_PEAK_GBS,
+        "roofline": roofline, "kernels": per_kernel,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        del model
+        cb, cpu_ids, ids = cpu_baseline(shape, L, base_sd, adapter_sd, a.spec_steps, a.threshold)
+        # same prompt on the device: token identity with the CPU path
+        dev_ids, _ = eng.generate(ids[0], 32, mode="kangaroo", **kw)
+        n = min(len(dev_ids), len(cpu_ids))
+        same = next((i for i in range(n) if dev_ids[i] != cpu_ids[i]), n)
+        cb["identical_tokens_vs_gpu"] = f"{same - ids.shape[1]}/{n - ids.shape[1]} new tokens before the first difference"
+        res["cpu_baseline"] = cb
+    elif rank == 0:
+        res["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -162,6 +162,16 @@ int kg_generate(kg_session* s, int mode, const int32_t* prompt_host, int context
                 int32_t* out_tokens_host, int32_t* accept_log_host, int accept_log_capacity,
                 kg_gen_result* result, void* stream);
 
+/* Measurement aid (no counterpart in the reference): replays `iters` launches of one of
+ * the session's linear kernels, cycling over the layers' weights so that no launch finds
+ * its weights in the Infinity Cache, from a captured graph on the session's own stream,
+ * and returns the mean microseconds per launch measured with HIP events on that stream.
+ * op: 0 qkv(+RMSNorm, RoPE, KV append) 1 o_proj(+residual) 2 gate/up(+RMSNorm, SiLU*mul)
+ * 3 down_proj(+residual) 4 lm_head(+RMSNorm, argmax partials).  rows == 1 times the GEMV,
+ * rows > 1 the MFMA kernel as the verify pass launches it.  Overwrites KV slots
+ * [0, rows) and the activation workspace: call it between generations only. */
+int kg_bench_op(kg_session* s, int op, int rows, int iters, float* us_per_launch, size_t* weight_bytes_per_launch);
+
 #ifdef __cplusplus
 }
 #endif

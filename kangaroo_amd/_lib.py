@@ -63,6 +63,7 @@ SYMBOLS = {
     "kg_final_norm": (_I, [_VP, _VP, _I, _VP, _VP]),
     "kg_adapter_forward": (_I, [_VP, _VP, _I, _I, _VP, _VP]),
     "kg_head_logits": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
+    "kg_bench_op": (_I, [_VP, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_size_t)]),
     "kg_generate": (_I, [_VP, _I, C.POINTER(C.c_int32), _I, _I, _I, _I, _D, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I,
                          C.POINTER(KgGenResult), _VP]),
 }

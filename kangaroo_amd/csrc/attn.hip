@@ -32,7 +32,10 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_kernel(const KgAttnArgs a
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane % LPR, rsub = lane / LPR;
 
-    int chunk = (len + nsplit - 1) / nsplit;
+    // Split boundaries depend only on the cache size, never on the current length: a row's
+    // keys are then summed in the same order whether it is decoded alone or verified
+    // together with later rows, which keeps verify and plain decoding bit-identical.
+    int chunk = (a.t_max + nsplit - 1) / nsplit;
     chunk = (chunk + BR - 1) / BR * BR;
     const int tbeg = split * chunk, tend = min(len, tbeg + chunk);
 

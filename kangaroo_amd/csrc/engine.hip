@@ -128,7 +128,7 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     carve(s, c, shape, buffers->t_max);
     s->prefill_rows = prefill_rows_for(shape);
     s->vec_bpc = 4; s->mfma_bpc = 2; s->vec_waves = 8; s->mfma_waves = 8;
-    s->attn_nsplit = 8;
+    s->attn_nsplit = 16;
     s->round_graph = nullptr; s->round_graph_steps = -1; s->vanilla_graph = nullptr;
     if (hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking) != hipSuccess) { delete s; return fail(-2, "hipStreamCreate failed"); }
     if (hipHostMalloc((void**)&s->host_state, 4 * 64 * sizeof(int)) != hipSuccess) { delete s; return fail(-2, "hipHostMalloc failed"); }
@@ -384,14 +384,18 @@ static int enqueue_round(kg_session* s, int steps, hipStream_t st) {
 }
 
 static int enqueue_vanilla(kg_session* s, hipStream_t st) {
+    // Plain greedy decoding, one token per replay.  The shallow layers run the q=1 GEMV
+    // kernels exactly as a draft step does; the remaining layers and the head run the
+    // MFMA kernels with one valid row, i.e. the arithmetic of a verify row.  Token for
+    // token the result is therefore bit-identical to the Kangaroo loop's output.
     const kg_shape& sh = s->sh;
     KgLoopBufs b = loop_bufs(s);
     KG_TRY(kg_launch_vanilla_begin(b, st));
     KG_TRY(kg_launch_embed(s->dyn_shallow, s->tokens, s->w.embed, sh.hidden_size, s->h, sh.hidden_size, st));
     for (int l = 0; l < sh.num_layers; ++l)
-        KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_shallow, 1, s->h, s->h, st));
+        KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_shallow, l < sh.exit_layer ? 1 : 2, s->h, s->h, st));
     int nb = 0;
-    KG_TRY(run_head(s, s->dyn_shallow, 1, s->h, 0, s->w.final_norm, nullptr, &nb, st));
+    KG_TRY(run_head(s, s->dyn_shallow, 2, s->h, 0, s->w.final_norm, nullptr, &nb, st));
     KG_TRY(kg_launch_vanilla_end(b, s->head_part, nb, st));
     return 0;
 }
@@ -543,6 +547,67 @@ extern "C" int kg_generate(kg_session* s, int mode, const int32_t* prompt_host, 
         if (n > accept_log_capacity) n = accept_log_capacity;
         if (n > 0) KG_CHECK_HIP(hipMemcpy(accept_log_host, s->state + KS_HDR, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost));
     }
+    return 0;
+}
+
+extern "C" int kg_bench_op(kg_session* s, int op, int rows, int iters, float* us_per_launch, size_t* weight_bytes_per_launch) {
+    g_err.clear();
+    if (!s || !us_per_launch || op < 0 || op > 4 || rows < 1 || rows > KG_MAX_ROWS || iters < 1 || iters > 4096) return fail(-1, "bad argument");
+    hipStream_t st = s->own_stream;
+    const kg_shape& sh = s->sh;
+    const int d = sh.hidden_size, F = sh.intermediate_size, dt = sh.dtype, N = sh.num_layers;
+    const int nw = waves_for(s, rows);
+    KG_TRY(kg_launch_set_dyn(s->dyn_call, 1, rows, 0, st));
+    KG_CHECK_HIP(hipStreamSynchronize(st));
+    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+    KG_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+    int rc = 0;
+    size_t wbytes = 0;
+    for (int i = 0; i < iters && rc == 0; ++i) {
+        const kg_layer_weights& lw = s->layers[i % N];
+        if (op == 0) {
+            KgLinArgs a = lin_base(s->dyn_call, lw.wqkv, s->q_dim + 2 * s->kv_dim, d, s->h, d);
+            a.norm_w = lw.norm1; a.eps = sh.rms_eps; a.q_out = s->xq; a.k_cache = layer_k(s, i % N); a.v_cache = layer_v(s, i % N);
+            a.rope_cos = s->w.rope_cos; a.rope_sin = s->w.rope_sin; a.head_dim = sh.head_dim; a.q_dim = s->q_dim; a.kv_dim = s->kv_dim; a.t_max = s->buf.t_max;
+            wbytes = (size_t)a.N * d * 2;
+            rc = kg_launch_linear(a, dt, rows, PRO_RMSNORM, EPI_ROPE_KV, grid_for(s, a.N, rows), nw, st);
+        } else if (op == 1) {
+            KgLinArgs a = lin_base(s->dyn_call, lw.wo, d, s->q_dim, s->attn_out, s->q_dim);
+            a.out = s->h2; a.out_stride = d; a.resid = s->h; a.resid_stride = d;
+            wbytes = (size_t)d * s->q_dim * 2;
+            rc = kg_launch_linear(a, dt, rows, PRO_NONE, EPI_RESID, grid_for(s, a.N, rows), nw, st);
+        } else if (op == 2) {
+            KgLinArgs a = lin_base(s->dyn_call, lw.wgu, 2 * F, d, s->h, d);
+            a.norm_w = lw.norm2; a.eps = sh.rms_eps; a.out = s->act; a.out_stride = F;
+            wbytes = (size_t)2 * F * d * 2;
+            rc = kg_launch_linear(a, dt, rows, PRO_RMSNORM, EPI_SILU_MUL, grid_for(s, a.N, rows), nw, st);
+        } else if (op == 3) {
+            KgLinArgs a = lin_base(s->dyn_call, lw.wdown, d, F, s->act, F);
+            a.out = s->h2; a.out_stride = d; a.resid = s->h; a.resid_stride = d;
+            wbytes = (size_t)d * F * 2;
+            rc = kg_launch_linear(a, dt, rows, PRO_NONE, EPI_RESID, grid_for(s, a.N, rows), nw, st);
+        } else {
+            int nb = 0;
+            wbytes = (size_t)sh.vocab_size * d * 2;
+            rc = run_head(s, s->dyn_call, rows, s->h, 0, s->w.final_norm, nullptr, &nb, st);
+        }
+    }
+    hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc != 0) { if (g) hipGraphDestroy(g); return fail(rc, "launch refused"); }
+    if (e != hipSuccess) { kg_set_error("hipStreamEndCapture", e); return -2; }
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) { kg_set_error("hipGraphInstantiate", e); return -2; }
+    KG_CHECK_HIP(hipGraphLaunch(ge, st));              // warm-up
+    KG_CHECK_HIP(hipEventRecord(s->ev_t0, st));
+    KG_CHECK_HIP(hipGraphLaunch(ge, st));
+    KG_CHECK_HIP(hipEventRecord(s->ev_t1, st));
+    KG_CHECK_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, s->ev_t0, s->ev_t1);
+    hipGraphExecDestroy(ge);
+    *us_per_launch = ms * 1000.f / iters;
+    if (weight_bytes_per_launch) *weight_bytes_per_launch = wbytes;
     return 0;
 }
 

@@ -195,6 +195,16 @@ class KangarooEngine:
         ids = ids.reshape(-1)
         self.tokens[pos0:pos0 + ids.numel()] = ids.to(device=self.device, dtype=torch.int32)
 
+    def bench_op(self, op: str, rows: int, iters: int = 64):
+        """Mean microseconds per launch of one linear kernel of the path (HIP events on the
+        launching stream) and its weight bytes.  op: qkv | o | gateup | down | head."""
+        code = {"qkv": 0, "o": 1, "gateup": 2, "down": 3, "head": 4}[op]
+        us = C.c_float(0)
+        nbytes = C.c_size_t(0)
+        torch.cuda.synchronize()
+        _lib.check(self.lib.kg_bench_op(self._handle, code, rows, iters, C.byref(us), C.byref(nbytes)), "kg_bench_op")
+        return us.value, nbytes.value
+
     # ---- fused loops ---------------------------------------------------------------
     def generate(self, prompt_ids, max_new_tokens: int, mode: str = "kangaroo", steps: int = 6, threshold: float = 0.6,
                  eos_token_id: int = 2, max_length: Optional[int] = None):
