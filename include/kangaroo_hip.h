@@ -64,7 +64,7 @@ typedef struct {
 
 typedef struct {
     void* k_cache;             /* [num_layers][Hkv][t_max][hd] */
-    void* v_cache;
+    void* v_cache;             /* same, or [num_layers][Hkv][hd][t_max] when head_dim >= 32 and t_max % 32 == 0 */
     void* ak_cache;            /* adapter: [Hkv][t_max][hd] */
     void* av_cache;
     void* workspace;           /* >= kg_workspace_bytes(), zero-filled by the caller */
@@ -100,17 +100,20 @@ int kg_linear(int dtype, const void* w_packed, int N, int K, const void* x, int 
               void* scratch /* device, >= 256 B */, int nblocks, int nwaves, void* stream);
 
 /* Fused RMSNorm + QKV projection + RoPE + in-place KV append for n_rows rows at
- * positions pos0.. (adapter.py:170-189 with the cache growing by torch.cat there). */
+ * positions pos0.. (adapter.py:170-189 with the cache growing by torch.cat there).
+ * K cache [Hkv][t_max][hd]; V cache [Hkv][t_max][hd] (v_transposed 0) or [Hkv][hd][t_max]
+ * (v_transposed 1: the layout the MFMA attention kernel reads; head_dim 32/64/128 and
+ * t_max % 32 == 0). */
 int kg_qkv_rope_append(int dtype, const void* wqkv_packed, int d, int n_heads, int n_kv_heads, int head_dim,
                        const void* x, int n_rows, int pos0, const void* norm_w, float eps,
                        const float* rope_cos, const float* rope_sin,
-                       void* q_out, void* k_cache, void* v_cache, int t_max,
+                       void* q_out, void* k_cache, void* v_cache, int t_max, int v_transposed,
                        void* scratch, int nblocks, int nwaves, void* stream);
 
 /* Causal attention of n_rows query rows at positions pos0.. over the cache rows
  * [0, pos0 + n_rows) (adapter.py:191-221; the mask of :38-67 is the causal bound). */
 int kg_attention(int dtype, const void* q, int n_rows, int pos0, const void* k_cache, const void* v_cache,
-                 int n_heads, int n_kv_heads, int head_dim, int t_max, int nsplit,
+                 int n_heads, int n_kv_heads, int head_dim, int t_max, int v_transposed, int nsplit,
                  void* out, void* scratch /* device, kg_attention_scratch_bytes() */, void* stream);
 size_t kg_attention_scratch_bytes(int n_heads, int head_dim, int nsplit);
 
@@ -127,6 +130,9 @@ size_t kg_head_scratch_bytes(int vocab);
 size_t kg_workspace_bytes(const kg_shape* shape, int t_max);
 int kg_session_create(const kg_shape* shape, const kg_weights* weights, const kg_buffers* buffers, kg_session** out);
 int kg_session_destroy(kg_session* s);
+/* kg_session_get: "v_transposed" (layout of buffers.v_cache / av_cache the session expects:
+ * 1 when head_dim >= 32 and t_max % 32 == 0), "prefill_rows", or a tuning key; -1 if unknown. */
+int kg_session_get(kg_session* s, const char* key);
 /* tuning knobs: key in {"vec_blocks_per_cu","mfma_blocks_per_cu","vec_waves","mfma_waves","attn_nsplit"} */
 int kg_session_set(kg_session* s, const char* key, int value);
 

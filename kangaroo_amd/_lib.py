@@ -48,8 +48,8 @@ SYMBOLS = {
     "kg_version": (_I, []),
     "kg_last_error": (C.c_char_p, []),
     "kg_linear": (_I, [_I, _VP, _I, _I, _VP, _I, _I, _VP, _F, _I, _VP, _VP, _I, _VP, _I, _I, _VP]),
-    "kg_qkv_rope_append": (_I, [_I, _VP, _I, _I, _I, _I, _VP, _I, _I, _VP, _F, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _I, _VP]),
-    "kg_attention": (_I, [_I, _VP, _I, _I, _VP, _VP, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
+    "kg_qkv_rope_append": (_I, [_I, _VP, _I, _I, _I, _I, _VP, _I, _I, _VP, _F, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _I, _I, _VP]),
+    "kg_attention": (_I, [_I, _VP, _I, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "kg_attention_scratch_bytes": (_SZ, [_I, _I, _I]),
     "kg_head": (_I, [_I, _VP, _I, _I, _VP, _I, _I, _VP, _F, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "kg_head_scratch_bytes": (_SZ, [_I]),
@@ -57,6 +57,7 @@ SYMBOLS = {
     "kg_session_create": (_I, [C.POINTER(KgShape), C.POINTER(KgWeights), C.POINTER(KgBuffers), C.POINTER(_VP)]),
     "kg_session_destroy": (_I, [_VP]),
     "kg_session_set": (_I, [_VP, C.c_char_p, _I]),
+    "kg_session_get": (_I, [_VP, C.c_char_p]),
     "kg_session_ptr": (_VP, [_VP, C.c_char_p]),
     "kg_set_tokens": (_I, [_VP, C.POINTER(C.c_int32), _I, _I, _VP]),
     "kg_forward_layers": (_I, [_VP, _I, _I, _VP, _I, _I, _VP, _VP]),

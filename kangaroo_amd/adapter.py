@@ -31,8 +31,7 @@ class AdapterModel:
         return self
 
     def _views(self, length: int):
-        e = self.engine
-        return ((e.ak_cache[:, :length, :].unsqueeze(0), e.av_cache[:, :length, :].unsqueeze(0)),)
+        return (self.engine.adapter_kv_views(length),)
 
     @torch.no_grad()
     def forward_early_stop(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,

@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_kernel(const KgAttnArgs a
     const int kvh = h / (a.H / a.Hkv);
     constexpr int RPI = 64 / LPR;                  // cache rows per wave-level load
     constexpr int BR = ATT_U * RPI;                // rows per batch
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane % LPR, rsub = lane / LPR;
 
     // Split boundaries depend only on the cache size, never on the current length: a row's
@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_kernel(const KgAttnArgs a
             const int t = tb + u * RPI + rsub;
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
+                if (m >= mr) { sc[u][m] = -INFINITY; continue; }     // uniform: work follows the valid rows
                 float d = 0.f;
                 d = T::dot2(kv[u].x, qf[m].x, d);
                 d = T::dot2(kv[u].y, qf[m].y, d);
@@ -118,6 +119,7 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_kernel(const KgAttnArgs a
     // ---- merge the row groups of this wave (lanes that share c) ----
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
+        if (m >= mr) continue;
 #pragma unroll
         for (int o = LPR; o < 64; o <<= 1) {
             lsum[m] += __shfl_xor(lsum[m], o, 64);
@@ -163,6 +165,143 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_kernel(const KgAttnArgs a
     }
 }
 
+// ---------------------------------------------------------------------------------
+// MFMA variant (head_dim 32 / 64 / 128, V cached transposed [Hkv][hd][t_max]).
+// Per wave and 32 keys:  S^T = K q^T  as two 16-key tiles of v_mfma_f32_16x16x32 (A = K rows,
+// B = q^T, so every lane owns one query column and 8 keys), softmax statistics per column
+// with two cross-lane steps for ALL query rows at once, then  O += P V  with the same
+// instruction (A = P straight from the score registers, B = V^T rows, 16 head dims per
+// MFMA).  The key <-> MFMA-row assignment of the two score tiles is chosen so that the 8
+// probabilities a lane holds are 8 consecutive keys, i.e. one 16-byte piece of a V^T row.
+// Cost is independent of the number of query rows (<= 16), so the verify pass, prefill
+// chunks and single-token decode share it, and a row's result does not depend on which
+// other rows ride along (columns of an MFMA are independent).
+template <int DT, int HD>
+__global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnArgs a) {
+    typedef KgT<DT> T;
+    const KgDyn* dyn = a.dyn;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int pos_c = dyn->pos[c];
+    if (dyn->active == 0) return;
+    const int M = dyn->n_rows;
+    const int len = dyn->pos[M - 1] + 1;
+    const int h = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+    const int kvh = h / (a.H / a.Hkv);
+    constexpr int KS = HD / 32;                    // k-steps of the score MFMAs
+    constexpr int DB = HD / 16;                    // 16-wide head-dim blocks of the output
+    int chunk = (a.t_max + nsplit - 1) / nsplit;   // fixed split boundaries (see kg_attn_kernel)
+    chunk = (chunk + 31) / 32 * 32;
+    const int tbeg = split * chunk, tend = min(len, tbeg + chunk);
+    const int lim = (c < M) ? pos_c : -1;          // causal bound of this lane's query column
+
+    kg_u4 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        kg_u4 z = {0u, 0u, 0u, 0u};
+        qf[s] = (c < M) ? *((const kg_u4*)((const unsigned short*)a.q + ((size_t)c * a.H + h) * HD + 32 * s + 8 * g)) : z;
+    }
+    float mrun = -INFINITY, lsum = 0.f;
+    kg_f4 O[DB];
+#pragma unroll
+    for (int b = 0; b < DB; ++b) O[b] = kg_f4{0.f, 0.f, 0.f, 0.f};
+    const float inv_scale = sqrtf((float)HD);
+    const unsigned short* kbase = (const unsigned short*)a.k_cache + (size_t)kvh * a.t_max * HD;
+    const unsigned short* vbase = (const unsigned short*)a.v_cache + (size_t)kvh * HD * a.t_max;
+    const int krow = 8 * (c >> 2) + (c & 3);       // tile 0: MFMA row c <-> key tb + krow; tile 1: + 4
+
+    for (int tb = tbeg + 32 * wave; tb < tend; tb += 32 * ATT_NW) {
+        kg_u4 kf[2][KS], vf[DB];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                kf[t][s] = *((const kg_u4*)(kbase + (size_t)(tb + krow + 4 * t) * HD + 32 * s + 8 * g));
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+            vf[b] = *((const kg_u4*)(vbase + (size_t)(16 * b + c) * a.t_max + tb + 8 * g));
+        float sc[8];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            kg_f4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) d = T::mfma(kf[t][s], qf[s], d);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = tb + 8 * g + 4 * t + i;
+                // reference op boundaries: q.k^T stored, then divided by sqrt(hd) and stored
+                const float v = kg_round<DT>(kg_round<DT>(d[i]) / inv_scale);
+                sc[4 * t + i] = (key < tend && key <= lim) ? v : -INFINITY;
+                bm = fmaxf(bm, sc[4 * t + i]);
+            }
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float mnew = fmaxf(mrun, bm);
+        const float scale = (mrun == -INFINITY) ? 0.f : expf(mrun - mnew);     // mnew == -inf only if mrun is too
+        unsigned short ph[8];
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float p = (sc[j] == -INFINITY) ? 0.f : expf(sc[j] - mnew);
+            psum += p;
+            ph[j] = T::from_f(p);
+        }
+        lsum = lsum * scale + psum;
+        mrun = mnew;
+        kg_u4 pf;
+        pf.x = ph[0] | ((unsigned)ph[1] << 16); pf.y = ph[2] | ((unsigned)ph[3] << 16);
+        pf.z = ph[4] | ((unsigned)ph[5] << 16); pf.w = ph[6] | ((unsigned)ph[7] << 16);
+        // accumulator rows are query rows 4g..4g+3: fetch their rescale factors from the
+        // lanes of this 16-lane group that own those columns
+        float f[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = __shfl(scale, (lane & 48) | (4 * g + i), 64);
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) O[b][i] *= f[i];
+            O[b] = T::mfma(pf, vf[b], O[b]);
+        }
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+
+    // ---- merge waves through LDS ----
+    __shared__ float s_o[ATT_NW][KG_MAX_ROWS][HD];
+    __shared__ float s_ml[ATT_NW][KG_MAX_ROWS][2];
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_o[wave][4 * g + i][16 * b + c] = O[b][i];
+    if (g == 0) { s_ml[wave][c][0] = mrun; s_ml[wave][c][1] = lsum; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < M * HD; i += blockDim.x) {
+        const int m = i / HD, dmi = i - m * HD;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < ATT_NW; ++w) mx = fmaxf(mx, s_ml[w][m][0]);
+        float o = 0.f, l = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATT_NW; ++w) {
+            const float wm = s_ml[w][m][0];
+            const float fw = (wm == -INFINITY) ? 0.f : expf(wm - mx);
+            o += fw * s_o[w][m][dmi];
+            l += fw * s_ml[w][m][1];
+        }
+        if (nsplit == 1) {
+            ((unsigned short*)a.out)[((size_t)m * a.H + h) * HD + dmi] = T::from_f(o / l);
+        } else {
+            a.part_o[(((size_t)split * a.max_rows + m) * a.H + h) * HD + dmi] = o;
+            if (dmi == 0) {
+                float* ml = a.part_ml + (((size_t)split * a.max_rows + m) * a.H + h) * 2;
+                ml[0] = mx; ml[1] = l;
+            }
+        }
+    }
+}
+
 // out[m][h][:] = sum_s w_s o_s / sum_s w_s l_s,  w_s = exp(m_s - max_s m_s)
 template <int DT>
 __global__ void kg_attn_combine_kernel(const KgAttnArgs a) {
@@ -199,12 +338,22 @@ static void launch_lpr(const KgAttnArgs& a, hipStream_t st) {
 }
 template <int DT>
 static int launch_dt(const KgAttnArgs& a, hipStream_t st) {
-    switch (a.hd) {
-    case 16: launch_lpr<DT, 2>(a, st); break;
-    case 32: launch_lpr<DT, 4>(a, st); break;
-    case 64: launch_lpr<DT, 8>(a, st); break;
-    case 128: launch_lpr<DT, 16>(a, st); break;
-    default: return -1;
+    if (a.v_transposed) {
+        dim3 grid(a.H, a.nsplit, 1);
+        switch (a.hd) {
+        case 32: hipLaunchKernelGGL((kg_attn_mfma_kernel<DT, 32>), grid, dim3(ATT_NW * 64), 0, st, a); break;
+        case 64: hipLaunchKernelGGL((kg_attn_mfma_kernel<DT, 64>), grid, dim3(ATT_NW * 64), 0, st, a); break;
+        case 128: hipLaunchKernelGGL((kg_attn_mfma_kernel<DT, 128>), grid, dim3(ATT_NW * 64), 0, st, a); break;
+        default: return -1;
+        }
+    } else {
+        switch (a.hd) {
+        case 16: launch_lpr<DT, 2>(a, st); break;
+        case 32: launch_lpr<DT, 4>(a, st); break;
+        case 64: launch_lpr<DT, 8>(a, st); break;
+        case 128: launch_lpr<DT, 16>(a, st); break;
+        default: return -1;
+        }
     }
     if (a.nsplit > 1) {
         dim3 grid(a.H, a.max_rows);
@@ -215,6 +364,7 @@ static int launch_dt(const KgAttnArgs& a, hipStream_t st) {
 
 int kg_launch_attn(const KgAttnArgs& a, int dtype, hipStream_t st) {
     if (a.nsplit < 1 || a.max_rows < 1 || a.max_rows > KG_MAX_ROWS || a.H % a.Hkv != 0) return -1;
+    if (a.v_transposed && (a.t_max % 32 != 0)) return -1;
     int rc = (dtype == KG_F16) ? launch_dt<KG_F16>(a, st) : launch_dt<KG_BF16>(a, st);
     if (rc) return rc;
     return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -46,6 +46,7 @@ struct kg_session {
     int prefill_rows;
     // tuning
     int vec_bpc, mfma_bpc, vec_waves, mfma_waves, attn_nsplit;
+    int v_transposed;
     // graphs
     hipStream_t own_stream;
     hipGraphExec_t round_graph; int round_graph_steps;
@@ -127,7 +128,8 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     Carver c{(char*)buffers->workspace, 0};
     carve(s, c, shape, buffers->t_max);
     s->prefill_rows = prefill_rows_for(shape);
-    s->vec_bpc = 4; s->mfma_bpc = 2; s->vec_waves = 8; s->mfma_waves = 8;
+    s->vec_bpc = 2; s->mfma_bpc = 1; s->vec_waves = 8; s->mfma_waves = 8;
+    s->v_transposed = (shape->head_dim >= 32 && buffers->t_max % 32 == 0) ? 1 : 0;
     s->attn_nsplit = 16;
     s->round_graph = nullptr; s->round_graph_steps = -1; s->vanilla_graph = nullptr;
     if (hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking) != hipSuccess) { delete s; return fail(-2, "hipStreamCreate failed"); }
@@ -167,6 +169,19 @@ extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
     if (s->round_graph) { hipGraphExecDestroy(s->round_graph); s->round_graph = nullptr; s->round_graph_steps = -1; }
     if (s->vanilla_graph) { hipGraphExecDestroy(s->vanilla_graph); s->vanilla_graph = nullptr; }
     return 0;
+}
+
+extern "C" int kg_session_get(kg_session* s, const char* key) {
+    if (!s || !key) return -1;
+    std::string k(key);
+    if (k == "v_transposed") return s->v_transposed;
+    if (k == "vec_blocks_per_cu") return s->vec_bpc;
+    if (k == "mfma_blocks_per_cu") return s->mfma_bpc;
+    if (k == "vec_waves") return s->vec_waves;
+    if (k == "mfma_waves") return s->mfma_waves;
+    if (k == "attn_nsplit") return s->attn_nsplit;
+    if (k == "prefill_rows") return s->prefill_rows;
+    return -1;
 }
 
 extern "C" void* kg_session_ptr(kg_session* s, const char* name) {
@@ -210,14 +225,14 @@ static int run_layer(kg_session* s, const kg_layer_weights& lw, void* kc, void* 
         a.norm_w = lw.norm1; a.eps = sh.rms_eps;
         a.q_out = s->xq; a.k_cache = kc; a.v_cache = vc;
         a.rope_cos = s->w.rope_cos; a.rope_sin = s->w.rope_sin;
-        a.head_dim = sh.head_dim; a.q_dim = s->q_dim; a.kv_dim = s->kv_dim; a.t_max = s->buf.t_max;
+        a.head_dim = sh.head_dim; a.q_dim = s->q_dim; a.kv_dim = s->kv_dim; a.t_max = s->buf.t_max; a.v_transposed = s->v_transposed;
         KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_RMSNORM, EPI_ROPE_KV, grid_for(s, a.N, max_rows), nw, st));
     }
     {
         KgAttnArgs a;
         memset(&a, 0, sizeof(a));
         a.dyn = dyn; a.q = s->xq; a.k_cache = kc; a.v_cache = vc;
-        a.H = sh.num_heads; a.Hkv = sh.num_kv_heads; a.hd = sh.head_dim; a.t_max = s->buf.t_max;
+        a.H = sh.num_heads; a.Hkv = sh.num_kv_heads; a.hd = sh.head_dim; a.t_max = s->buf.t_max; a.v_transposed = s->v_transposed;
         a.nsplit = s->attn_nsplit; a.part_o = s->part_o; a.part_ml = s->part_ml; a.out = s->attn_out; a.max_rows = max_rows;
         KG_TRY(kg_launch_attn(a, dt, st));
     }
@@ -568,7 +583,7 @@ extern "C" int kg_bench_op(kg_session* s, int op, int rows, int iters, float* us
         if (op == 0) {
             KgLinArgs a = lin_base(s->dyn_call, lw.wqkv, s->q_dim + 2 * s->kv_dim, d, s->h, d);
             a.norm_w = lw.norm1; a.eps = sh.rms_eps; a.q_out = s->xq; a.k_cache = layer_k(s, i % N); a.v_cache = layer_v(s, i % N);
-            a.rope_cos = s->w.rope_cos; a.rope_sin = s->w.rope_sin; a.head_dim = sh.head_dim; a.q_dim = s->q_dim; a.kv_dim = s->kv_dim; a.t_max = s->buf.t_max;
+            a.rope_cos = s->w.rope_cos; a.rope_sin = s->w.rope_sin; a.head_dim = sh.head_dim; a.q_dim = s->q_dim; a.kv_dim = s->kv_dim; a.t_max = s->buf.t_max; a.v_transposed = s->v_transposed;
             wbytes = (size_t)a.N * d * 2;
             rc = kg_launch_linear(a, dt, rows, PRO_RMSNORM, EPI_ROPE_KV, grid_for(s, a.N, rows), nw, st);
         } else if (op == 1) {
@@ -639,7 +654,7 @@ extern "C" int kg_linear(int dtype, const void* w_packed, int N, int K, const vo
 extern "C" int kg_qkv_rope_append(int dtype, const void* wqkv_packed, int d, int n_heads, int n_kv_heads, int head_dim,
                                   const void* x, int n_rows, int pos0, const void* norm_w, float eps,
                                   const float* rope_cos, const float* rope_sin,
-                                  void* q_out, void* k_cache, void* v_cache, int t_max,
+                                  void* q_out, void* k_cache, void* v_cache, int t_max, int v_transposed,
                                   void* scratch, int nblocks, int nwaves, void* stream) {
     g_err.clear();
     kg_init_once();
@@ -651,7 +666,7 @@ extern "C" int kg_qkv_rope_append(int dtype, const void* wqkv_packed, int d, int
     const int qd = n_heads * head_dim, kvd = n_kv_heads * head_dim;
     KgLinArgs a = lin_base(dyn, wqkv_packed, qd + 2 * kvd, d, x, d);
     a.norm_w = norm_w; a.eps = eps; a.q_out = q_out; a.k_cache = k_cache; a.v_cache = v_cache;
-    a.rope_cos = rope_cos; a.rope_sin = rope_sin; a.head_dim = head_dim; a.q_dim = qd; a.kv_dim = kvd; a.t_max = t_max;
+    a.rope_cos = rope_cos; a.rope_sin = rope_sin; a.head_dim = head_dim; a.q_dim = qd; a.kv_dim = kvd; a.t_max = t_max; a.v_transposed = v_transposed ? 1 : 0;
     int rc = kg_launch_linear(a, dtype, n_rows, PRO_RMSNORM, EPI_ROPE_KV, nblocks > 0 ? nblocks : g_ncu * 2, nwaves > 0 ? nwaves : 8, st);
     if (rc) return fail(rc, "kg_launch_linear failed");
     return 0;
@@ -662,7 +677,7 @@ extern "C" size_t kg_attention_scratch_bytes(int n_heads, int head_dim, int nspl
 }
 
 extern "C" int kg_attention(int dtype, const void* q, int n_rows, int pos0, const void* k_cache, const void* v_cache,
-                            int n_heads, int n_kv_heads, int head_dim, int t_max, int nsplit,
+                            int n_heads, int n_kv_heads, int head_dim, int t_max, int v_transposed, int nsplit,
                             void* out, void* scratch, void* stream) {
     g_err.clear();
     kg_init_once();
@@ -673,14 +688,14 @@ extern "C" int kg_attention(int dtype, const void* q, int n_rows, int pos0, cons
     KG_TRY(kg_launch_set_dyn(dyn, 1, n_rows, pos0, st));
     KgAttnArgs a;
     memset(&a, 0, sizeof(a));
-    a.dyn = dyn; a.q = q; a.k_cache = k_cache; a.v_cache = v_cache; a.H = n_heads; a.Hkv = n_kv_heads; a.hd = head_dim; a.t_max = t_max;
+    a.dyn = dyn; a.q = q; a.k_cache = k_cache; a.v_cache = v_cache; a.H = n_heads; a.Hkv = n_kv_heads; a.hd = head_dim; a.t_max = t_max; a.v_transposed = v_transposed ? 1 : 0;
     a.nsplit = nsplit; a.max_rows = n_rows;
     a.part_o = (float*)((char*)scratch + 256);
     a.part_ml = a.part_o + (size_t)nsplit * KG_MAX_ROWS * n_heads * head_dim;
     // partial buffers are indexed with max_rows = n_rows, within the KG_MAX_ROWS-sized scratch
     a.out = out;
     int rc = kg_launch_attn(a, dtype, st);
-    if (rc) return fail(rc, "kg_launch_attn failed (head_dim must be 16/32/64/128)");
+    if (rc) return fail(rc, "kg_launch_attn failed (head_dim 16/32/64/128; transposed V needs head_dim >= 32 and t_max % 32 == 0)");
     return 0;
 }
 

@@ -20,9 +20,11 @@ struct KgLinArgs {
     void* q_out; void* k_cache; void* v_cache;
     const float* rope_cos; const float* rope_sin;   // [max_pos, head_dim/2]
     int head_dim, q_dim, kv_dim, t_max;
+    int v_transposed;                               // v_cache layout [Hkv, hd, t_max] instead of [Hkv, t_max, hd]
     // EPI_HEAD
     float* head_part; int head_part_stride;         // [rows][head_part_stride][4]
     void* logits_out; int logits_stride;            // optional
+    int side_bytes;                                 // set by the launcher: LDS bytes of staged epilogue inputs
 };
 
 size_t kg_linear_smem(int mfma, int max_rows, int K, int nwaves);
@@ -35,6 +37,7 @@ struct KgAttnArgs {
     const void* k_cache;        // [Hkv, t_max, hd]
     const void* v_cache;
     int H, Hkv, hd, t_max;
+    int v_transposed;           // 1: v_cache is [Hkv, hd, t_max] and the MFMA kernel runs (hd 32/64/128, t_max % 32 == 0)
     int nsplit;
     float* part_o;              // [nsplit][rows][H][hd]
     float* part_ml;             // [nsplit][rows][H][2]

@@ -55,22 +55,18 @@ __device__ __forceinline__ void head_merge(HeadRun& a, float bmx, float bsum, in
 
 // Epilogue for one (row pair, column m).  n0 = packed row index of v0; v1 is row n0+1.
 template <int DT, int EPI>
-__device__ __forceinline__ void epilogue_pair(const KgLinArgs& a, int n0, int m, int pos, float v0, float v1, HeadRun& run) {
+__device__ __forceinline__ void epilogue_pair(const KgLinArgs& a, int n0, int m, int pos, float v0, float v1, HeadRun& run,
+                                              const char* side, int it, int M) {
     typedef KgT<DT> T;
     unsigned short* out = (unsigned short*)a.out;
     if (EPI == EPI_STORE) {
         if (n0 < a.N) out[(size_t)m * a.out_stride + n0] = T::from_f(v0);
         if (n0 + 1 < a.N) out[(size_t)m * a.out_stride + n0 + 1] = T::from_f(v1);
     } else if (EPI == EPI_RESID) {
-        const unsigned short* res = (const unsigned short*)a.resid;
-        if (n0 < a.N) {
-            float r = T::to_f(res[(size_t)m * a.resid_stride + n0]);
-            out[(size_t)m * a.out_stride + n0] = T::from_f(r + kg_round<DT>(v0));
-        }
-        if (n0 + 1 < a.N) {
-            float r = T::to_f(res[(size_t)m * a.resid_stride + n0 + 1]);
-            out[(size_t)m * a.out_stride + n0 + 1] = T::from_f(r + kg_round<DT>(v1));
-        }
+        // residual rows of this block were staged in LDS by the prologue: [it][m][16]
+        const unsigned short* res = (const unsigned short*)side + ((size_t)it * M + m) * 16 + (n0 & 15);
+        if (n0 < a.N) out[(size_t)m * a.out_stride + n0] = T::from_f(T::to_f(res[0]) + kg_round<DT>(v0));
+        if (n0 + 1 < a.N) out[(size_t)m * a.out_stride + n0 + 1] = T::from_f(T::to_f(res[1]) + kg_round<DT>(v1));
     } else if (EPI == EPI_SILU_MUL) {
         // packed rows (2i, 2i+1) = (gate_i, up_i)
         int i = n0 >> 1;
@@ -82,8 +78,10 @@ __device__ __forceinline__ void epilogue_pair(const KgLinArgs& a, int n0, int m,
         const int head = n0 / hd, hl = n0 - head * hd, j = hl >> 1;
         float x1 = kg_round<DT>(v0), x2 = kg_round<DT>(v1);
         if (n0 < a.q_dim + a.kv_dim) {
-            float c = kg_round<DT>(a.rope_cos[(size_t)pos * half + j]);
-            float s = kg_round<DT>(a.rope_sin[(size_t)pos * half + j]);
+            // cos / sin rows of the pass's positions were staged in LDS: [m][2][hd/2]
+            const float* cs = (const float*)side + (size_t)m * hd;
+            float c = kg_round<DT>(cs[j]);
+            float s = kg_round<DT>(cs[half + j]);
             float o1 = kg_round<DT>(x1 * c) + kg_round<DT>(-x2 * s);
             float o2 = kg_round<DT>(x2 * c) + kg_round<DT>(x1 * s);
             x1 = o1; x2 = o2;    // stored through from_f below (one more rounding, as the reference's add)
@@ -96,6 +94,12 @@ __device__ __forceinline__ void epilogue_pair(const KgLinArgs& a, int n0, int m,
             dst = (unsigned short*)a.k_cache + ((size_t)kvh * a.t_max + pos) * hd;
         } else {
             int kvh = head - (a.q_dim + a.kv_dim) / hd;
+            if (a.v_transposed) {
+                unsigned short* vt = (unsigned short*)a.v_cache + (size_t)kvh * hd * a.t_max + pos;
+                vt[(size_t)j * a.t_max] = T::from_f(x1);
+                vt[(size_t)(j + half) * a.t_max] = T::from_f(x2);
+                return;
+            }
             dst = (unsigned short*)a.v_cache + ((size_t)kvh * a.t_max + pos) * hd;
         }
         dst[j] = T::from_f(x1);
@@ -113,40 +117,121 @@ __device__ __forceinline__ void epilogue_pair(const KgLinArgs& a, int n0, int m,
 }
 
 // ---- prologue: fill X rows in LDS -------------------------------------------------
-// xs: LDS base of X, row stride xs_stride bytes.  Each wave takes rows m = wave, wave+W, ...
-template <int DT, int PRO>
-__device__ __forceinline__ void prologue_fill(const KgLinArgs& a, char* xs, int xs_stride, int M, int row_off, int wave, int nwaves, int lane) {
+// xs: LDS base of X, row stride xs_stride bytes.  The whole block works on every row:
+// thread t owns the 16-byte chunks t, t + blockDim, ... of each row, so the sum of squares
+// of a row is formed in the same order whatever the number of rows in the pass.
+//
+// Fast path (a row has at most one chunk per thread): prologue_load issues the chunks of
+// all rows as range-checked buffer loads BEFORE the first weight tiles are requested and
+// keeps them in registers; prologue_finish runs after the weight loads are in flight, so
+// the norm and the LDS fill overlap the first HBM round trip (the memory counter retires
+// in order: x requested first is waited for with the weight loads still outstanding).
+template <int RM> struct ProRegs { kg_u4 v[RM]; kg_u4 gw; };
+
+template <int DT, int PRO, int RM>
+__device__ __forceinline__ void prologue_slow(const KgLinArgs& a, char* xs, int xs_stride, float* red, int M, int row_off,
+                                              int tid, int nthreads) {
     typedef KgT<DT> T;
-    const int K = a.K;
-    const int nchunk = K >> 3;                      // 16-byte chunks per row
-    for (int m = wave; m < M; m += nwaves) {
+    const int K = a.K, nchunk = K >> 3;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    const kg_u4* wn = (const kg_u4*)a.norm_w;
+    if (PRO == PRO_NONE) {
+        for (int m = 0; m < M; ++m) {
+            const kg_u4* src = (const kg_u4*)((const unsigned short*)a.x + (size_t)(m + row_off) * a.x_stride);
+            kg_u4* dst = (kg_u4*)(xs + (size_t)m * xs_stride);
+            for (int c = tid; c < nchunk; c += nthreads) dst[c] = src[c];
+        }
+        return;
+    }
+    for (int m = 0; m < M; ++m) {
+        const kg_u4* src = (const kg_u4*)((const unsigned short*)a.x + (size_t)(m + row_off) * a.x_stride);
+        float ss = 0.f;
+        for (int c = tid; c < nchunk; c += nthreads) {
+            kg_us8 h = __builtin_bit_cast(kg_us8, src[c]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float f = T::to_f(h[j]); ss += f * f; }
+        }
+        ss = kg_wave_sum(ss);
+        if (lane == 0) red[m * nwaves + wave] = ss;
+    }
+    __syncthreads();
+    for (int m = 0; m < M; ++m) {
+        float tot = 0.f;
+        for (int w = 0; w < nwaves; ++w) tot += red[m * nwaves + w];
+        const float rstd = rsqrtf(tot / (float)K + a.eps);
         const kg_u4* src = (const kg_u4*)((const unsigned short*)a.x + (size_t)(m + row_off) * a.x_stride);
         kg_u4* dst = (kg_u4*)(xs + (size_t)m * xs_stride);
-        if (PRO == PRO_NONE) {
-            for (int c = lane; c < nchunk; c += 64) dst[c] = src[c];
-        } else {
+        for (int c = tid; c < nchunk; c += nthreads) {
+            kg_us8 h = __builtin_bit_cast(kg_us8, src[c]);
+            kg_us8 g = __builtin_bit_cast(kg_us8, wn[c]);
+            kg_us8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = kg_round<DT>(T::to_f(h[j]) * rstd);
+                o[j] = T::from_f(T::to_f(g[j]) * f);
+            }
+            dst[c] = __builtin_bit_cast(kg_u4, o);
+        }
+    }
+}
+
+template <int PRO, int RM>
+__device__ __forceinline__ void prologue_load(const KgLinArgs& a, ProRegs<RM>& pr, int M, int row_off, int tid) {
+    const int K = a.K, nchunk = K >> 3;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0,
+        (int)(((size_t)(M - 1 + row_off) * a.x_stride + K) * 2), 0x00020000);
+#pragma unroll
+    for (int m = 0; m < RM; ++m) {
+        const bool ok = (m < M) && (tid < nchunk);
+        const unsigned off = ok ? (unsigned)(((size_t)(m + row_off) * a.x_stride) * 2 + tid * 16) : 0xFFFFFFFFu;
+        pr.v[m] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+    }
+    if (PRO == PRO_RMSNORM) {
+        const __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc((void*)a.norm_w, 0, K * 2, 0x00020000);
+        pr.gw = __builtin_amdgcn_raw_buffer_load_b128(nr, (tid < nchunk) ? (unsigned)tid * 16u : 0xFFFFFFFFu, 0, 0);
+    }
+}
+
+template <int DT, int PRO, int RM>
+__device__ __forceinline__ void prologue_finish(const KgLinArgs& a, const ProRegs<RM>& pr, char* xs, int xs_stride, float* red, int M,
+                                                int tid, int nthreads) {
+    typedef KgT<DT> T;
+    const int K = a.K, nchunk = K >> 3;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    if (PRO == PRO_NONE) {
+#pragma unroll
+        for (int m = 0; m < RM; ++m)
+            if (m < M && tid < nchunk) *(kg_u4*)(xs + (size_t)m * xs_stride + tid * 16) = pr.v[m];
+        return;
+    }
+#pragma unroll
+    for (int m = 0; m < RM; ++m) {
+        if (m < M) {
+            kg_us8 h = __builtin_bit_cast(kg_us8, pr.v[m]);
             float ss = 0.f;
-            for (int c = lane; c < nchunk; c += 64) {
-                kg_u4 v = src[c];
-                kg_us8 h = __builtin_bit_cast(kg_us8, v);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { float f = T::to_f(h[j]); ss += f * f; }
-            }
+            for (int j = 0; j < 8; ++j) { float f = T::to_f(h[j]); ss += f * f; }
             ss = kg_wave_sum(ss);
-            const float rstd = rsqrtf(ss / (float)K + a.eps);
-            const kg_u4* wn = (const kg_u4*)a.norm_w;
-            for (int c = lane; c < nchunk; c += 64) {
-                kg_us8 h = __builtin_bit_cast(kg_us8, src[c]);
-                kg_us8 g = __builtin_bit_cast(kg_us8, wn[c]);
-                kg_us8 o;
+            if (lane == 0) red[m * nwaves + wave] = ss;
+        }
+    }
+    __syncthreads();
+    kg_us8 g = __builtin_bit_cast(kg_us8, pr.gw);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    // normalise in fp32, store in the model dtype, then scale by the weight
-                    float f = kg_round<DT>(T::to_f(h[j]) * rstd);
-                    o[j] = T::from_f(T::to_f(g[j]) * f);
-                }
-                dst[c] = __builtin_bit_cast(kg_u4, o);
+    for (int m = 0; m < RM; ++m) {
+        if (m < M) {
+            float tot = 0.f;
+            for (int w = 0; w < nwaves; ++w) tot += red[m * nwaves + w];
+            const float rstd = rsqrtf(tot / (float)K + a.eps);
+            kg_us8 h = __builtin_bit_cast(kg_us8, pr.v[m]);
+            kg_us8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // normalise in fp32, store in the model dtype, then scale by the weight
+                float f = kg_round<DT>(T::to_f(h[j]) * rstd);
+                o[j] = T::from_f(T::to_f(g[j]) * f);
             }
+            if (tid < nchunk) *(kg_u4*)(xs + (size_t)m * xs_stride + tid * 16) = __builtin_bit_cast(kg_u4, o);
         }
     }
 }
@@ -155,111 +240,209 @@ template <int DT, int MODE, int PRO, int EPI>
 __global__ void __launch_bounds__(512) kg_linear_kernel(const KgLinArgs a) {
     typedef KgT<DT> T;
     const KgDyn* dyn = a.dyn;
+    // wave index through readfirstlane: everything derived from it (k-range, loop counters,
+    // row-group cursor) is then provably wave-uniform and the loop's control flow is scalar
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
+    // one round trip for all per-pass parameters: switch, row count, positions (lane l holds pos[l])
+    const int posv = (EPI == EPI_ROPE_KV) ? dyn->pos[lane & (KG_MAX_ROWS - 1)] : 0;
     if (dyn->active == 0) return;
-    const int M = (MODE == MODE_VEC) ? 1 : dyn->n_rows;
+    const int n_rows = dyn->n_rows;
+    const int M = (MODE == MODE_VEC) ? 1 : n_rows;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    constexpr int RM = (MODE == MODE_VEC) ? 1 : KG_MAX_ROWS;
     const int PART = (MODE == MODE_VEC) ? 16 : 256;            // floats per wave partial
-    float* part = (float*)smem;                                  // [2][nwaves][PART]
-    char* xs = smem + 2 * nwaves * PART * 4;
+    char* side = smem;                                           // epilogue inputs staged once (residual rows / RoPE rows)
+    float* part = (float*)(smem + a.side_bytes);                 // [2][nwaves][PART]
+    char* xs = smem + a.side_bytes + 2 * nwaves * PART * 4;
+    const int my_pos = (EPI == EPI_ROPE_KV) ? __shfl(posv, (tid >> 3) & (KG_MAX_ROWS - 1), 64) : 0;
     const int xs_stride = a.K * 2 + 32;
+    const int nthreads = blockDim.x;
 
     const int G = (a.N + 15) >> 4, KT = a.K >> 5;
     const int t0 = (KT * wave) / nwaves, t1 = (KT * (wave + 1)) / nwaves;
-    const kg_u4* Wp = (const kg_u4*)a.W;
+    const int tlast = max(t1 - 1, 0);
     const int g = lane >> 4, r = lane & 15;
 
     // B-operand / x source for this lane
     const int mrow = (r < M) ? r : 0;
     const char* xl = xs + (size_t)((MODE == MODE_VEC) ? 0 : mrow) * xs_stride + g * 16;
-    const kg_u4* xg = (const kg_u4*)((const unsigned short*)a.x + (size_t)mrow * a.x_stride) + g;   // MODE_MFMA_GX
+
+    // ---- small loads first: X rows and what the epilogues need (residual rows, RoPE rows).
+    // A global load inside the streaming loop would have to be waited for with vmcnt(0),
+    // i.e. drain every weight tile in flight, so everything is fetched here and parked in LDS.
+    const int row_off = (MODE == MODE_VEC && a.x_last_row) ? n_rows - 1 : 0;
+    const bool pro_fast = (a.K >> 3) <= nthreads;
+    ProRegs<RM> pr;
+    if (MODE != MODE_MFMA_GX) {
+        if (pro_fast) prologue_load<PRO, RM>(a, pr, M, row_off, tid);
+        else prologue_slow<DT, PRO, RM>(a, xs, xs_stride, part, M, row_off, tid, nthreads);
+    }
+    unsigned side_raw[2] = {0u, 0u};
+    const int nrg_blk = (G - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int side_n = (EPI == EPI_RESID) ? nrg_blk * M * 16 : (EPI == EPI_ROPE_KV) ? M * a.head_dim : 0;
+    const bool side_fast = side_n <= 2 * nthreads;
+    if (EPI == EPI_RESID) {
+        if (side_fast) {
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)a.resid, 0,
+                (int)(((size_t)(M - 1) * a.resid_stride + a.N) * 2), 0x00020000);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = tid + e * nthreads;
+                const int row = i & 15, m = (i >> 4) % M, itx = (i >> 4) / M;
+                const int n = ((int)blockIdx.x + itx * (int)gridDim.x) * 16 + row;
+                const bool ok = (i < side_n) && (n < a.N);
+                side_raw[e] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, ok ? (unsigned)(((size_t)m * a.resid_stride + n) * 2) : 0xFFFFFFFFu, 0, 0);
+            }
+        } else {
+            const unsigned short* res = (const unsigned short*)a.resid;
+            unsigned short* sd = (unsigned short*)side;
+            for (int i = tid; i < side_n; i += nthreads) {
+                const int row = i & 15, m = (i >> 4) % M, itx = (i >> 4) / M;
+                const int n = ((int)blockIdx.x + itx * (int)gridDim.x) * 16 + row;
+                sd[i] = (n < a.N) ? res[(size_t)m * a.resid_stride + n] : (unsigned short)0;
+            }
+        }
+    } else if (EPI == EPI_ROPE_KV) {
+        const int half = a.head_dim >> 1;
+        if (side_fast) {
+            const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)a.rope_cos, 0, 0x7FFFFFF0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)a.rope_sin, 0, 0x7FFFFFF0, 0x00020000);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = tid + e * nthreads;
+                const int m = i / a.head_dim, jj = i - m * a.head_dim;
+                const int p = __shfl(posv, m & (KG_MAX_ROWS - 1), 64);
+                const bool ok = i < side_n;
+                const unsigned off = (unsigned)(((size_t)p * half + (jj < half ? jj : jj - half)) * 4);
+                const unsigned c = __builtin_amdgcn_raw_buffer_load_b32(cr, (ok && jj < half) ? off : 0xFFFFFFFFu, 0, 0);
+                const unsigned sn = __builtin_amdgcn_raw_buffer_load_b32(sr, (ok && jj >= half) ? off : 0xFFFFFFFFu, 0, 0);
+                side_raw[e] = c | sn;
+            }
+        } else {
+            float* sd = (float*)side;
+            for (int i = tid; i < side_n; i += nthreads) {
+                const int m = i / a.head_dim, jj = i - m * a.head_dim;
+                const int p = dyn->pos[m];
+                sd[i] = (jj < half) ? a.rope_cos[(size_t)p * half + jj] : a.rope_sin[(size_t)p * half + jj - half];
+            }
+        }
+    }
 
     int rg = blockIdx.x;
-    kg_u4 cur[KG_U], nxt[KG_U];
-    kg_u4 curx[KG_U], nxtx[KG_U];
-    const kg_u4* dummy = Wp + (size_t)lane;
+    kg_u4 bufA[KG_U], bufB[KG_U];
+    kg_u4 bufAx[KG_U], bufBx[KG_U];
 
+    // Weight tiles come through buffer loads: every load instruction is unconditional (so the
+    // compiler's counted waits stay exact and nothing branches around a load), and a tile
+    // past the wave's k-range or past the block's last row group gets an out-of-range
+    // offset, which the hardware range check answers with zeros without touching memory.
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (int)((size_t)G * KT * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0,
+        (MODE == MODE_MFMA_GX) ? (int)(((size_t)(M - 1) * a.x_stride + a.K) * 2) : 0, 0x00020000);
+    const unsigned xoff0 = (unsigned)(((size_t)mrow * a.x_stride) * 2 + g * 16);
     auto issue = [&](kg_u4 (&wv)[KG_U], kg_u4 (&xv)[KG_U], int lrg, int lt) {
-        const kg_u4* base = Wp + ((size_t)lrg * KT) * 64 + lane;
+        const unsigned base = (unsigned)lrg * (unsigned)KT * 1024u + (unsigned)lane * 16u;
 #pragma unroll
         for (int u = 0; u < KG_U; ++u) {
             const bool ok = (lrg < G) && (lt + u < t1);
-            const kg_u4* p = ok ? (base + (size_t)(lt + u) * 64) : dummy;
-            wv[u] = kg_ldg_stream(p);
+            const unsigned off = ok ? base + (unsigned)(lt + u) * 1024u : 0xFFFFFFFFu;
+            wv[u] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 2);
             if (MODE == MODE_MFMA_GX) {
-                const kg_u4* q = ok ? (xg + (size_t)(lt + u) * 4) : xg;
-                xv[u] = *q;
+                const unsigned xo = ok ? xoff0 + (unsigned)(lt + u) * 64u : 0xFFFFFFFFu;
+                xv[u] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo, 0, 0);
             }
         }
     };
 
+    // two batches of weight tiles in flight while the prologue finishes
     int lrg = rg, lt = t0;
-    issue(cur, curx, lrg, lt);
+    issue(bufA, bufAx, lrg, lt);
+    lt += KG_U;
+    if (lt >= t1) { lt = t0; lrg += gridDim.x; }
+    issue(bufB, bufBx, lrg, lt);
     lt += KG_U;
     if (lt >= t1) { lt = t0; lrg += gridDim.x; }
 
-    if (MODE != MODE_MFMA_GX) {
-        prologue_fill<DT, PRO>(a, xs, xs_stride, M, (MODE == MODE_VEC && a.x_last_row) ? dyn->n_rows - 1 : 0, wave, nwaves, lane);
-        __syncthreads();
+    if (side_fast) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = tid + e * nthreads;
+            if (i < side_n) {
+                if (EPI == EPI_RESID) ((unsigned short*)side)[i] = (unsigned short)side_raw[e];
+                if (EPI == EPI_ROPE_KV) ((unsigned*)side)[i] = side_raw[e];
+            }
+        }
     }
+    if (MODE != MODE_MFMA_GX && pro_fast) prologue_finish<DT, PRO, RM>(a, pr, xs, xs_stride, part, M, tid, nthreads);
+    __syncthreads();
 
     HeadRun run; run.mx = -INFINITY; run.sum = 0.f; run.idx = 0;
-    int it = 0;
-    for (; rg < G; rg += gridDim.x, ++it) {
-        kg_f4 acc = {0.f, 0.f, 0.f, 0.f};
-        float acc0 = 0.f, acc1 = 0.f;
-        for (int ct = t0; ct < t1; ct += KG_U) {
-            issue(nxt, nxtx, lrg, lt);
-            lt += KG_U;
-            if (lt >= t1) { lt = t0; lrg += gridDim.x; }
+    int it = 0, ct = t0;
+    kg_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    float acc0 = 0.f, acc1 = 0.f;
+
+    // One step: consume the batch held in (wv, xv), refill the same registers with the batch
+    // two ahead (the two buffers alternate, so no register copies and up to 2*KG_U tiles stay
+    // in flight per wave), and at the end of a row group reduce across waves and run the
+    // epilogue.
+    auto step = [&](kg_u4 (&wv)[KG_U], kg_u4 (&xv)[KG_U]) {
 #pragma unroll
-            for (int u = 0; u < KG_U; ++u) {
-                const bool ok = (ct + u < t1);
-                kg_u4 wv = cur[u];
-                if (!ok) { wv.x = 0; wv.y = 0; wv.z = 0; wv.w = 0; }
-                if (MODE == MODE_VEC) {
-                    const int tt = ok ? (ct + u) : t0;
-                    kg_u4 xv = *(const kg_u4*)(xl + (size_t)tt * 64);
-                    acc0 = T::dot2(wv.x, xv.x, acc0);
-                    acc1 = T::dot2(wv.y, xv.y, acc1);
-                    acc0 = T::dot2(wv.z, xv.z, acc0);
-                    acc1 = T::dot2(wv.w, xv.w, acc1);
-                } else if (MODE == MODE_MFMA) {
-                    const int tt = ok ? (ct + u) : t0;
-                    kg_u4 xv = *(const kg_u4*)(xl + (size_t)tt * 64);
-                    acc = T::mfma(wv, xv, acc);
-                } else {
-                    acc = T::mfma(wv, curx[u], acc);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < KG_U; ++u) { cur[u] = nxt[u]; if (MODE == MODE_MFMA_GX) curx[u] = nxtx[u]; }
-        }
-        // ---- cross-wave reduction through LDS (slot alternates per row group) ----
-        float* slot = part + (size_t)(it & 1) * nwaves * PART;
-        if (MODE == MODE_VEC) {
-            float v = acc0 + acc1;
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (lane < 16) slot[wave * 16 + lane] = v;
-        } else {
-            // lane holds D[row 4g+i][col r]; store as [col][row] so a pair reads 2 floats
-            *(kg_f4*)(slot + wave * 256 + r * 16 + g * 4) = acc;
-        }
-        __syncthreads();
-        const int n_epi = (MODE == MODE_VEC) ? 8 : 128;
-        if (tid < n_epi) {
-            const int m = tid >> 3, p = tid & 7;
-            if (m < M) {
-                float v0 = 0.f, v1 = 0.f;
-                for (int w = 0; w < nwaves; ++w) {
-                    const float* s = slot + w * PART + m * 16 + 2 * p;
-                    v0 += s[0]; v1 += s[1];
-                }
-                epilogue_pair<DT, EPI>(a, rg * 16 + 2 * p, m, dyn->pos[m], v0, v1, run);
+        for (int u = 0; u < KG_U; ++u) {
+            const kg_u4 w = wv[u];                    // zeros when the tile was out of range
+            const int tt = min(ct + u, tlast);
+            if (MODE == MODE_VEC) {
+                kg_u4 x = *(const kg_u4*)(xl + (size_t)tt * 64);
+                acc0 = T::dot2(w.x, x.x, acc0);
+                acc1 = T::dot2(w.y, x.y, acc1);
+                acc0 = T::dot2(w.z, x.z, acc0);
+                acc1 = T::dot2(w.w, x.w, acc1);
+            } else if (MODE == MODE_MFMA) {
+                kg_u4 x = *(const kg_u4*)(xl + (size_t)tt * 64);
+                acc = T::mfma(w, x, acc);
+            } else {
+                acc = T::mfma(w, xv[u], acc);
             }
         }
-    }
+        issue(wv, xv, lrg, lt);
+        lt += KG_U;
+        if (lt >= t1) { lt = t0; lrg += gridDim.x; }
+        ct += KG_U;
+        if (ct >= t1 && rg < G) {
+            // ---- cross-wave reduction through LDS (slot alternates per row group) ----
+            float* slot = part + (size_t)(it & 1) * nwaves * PART;
+            if (MODE == MODE_VEC) {
+                float v = acc0 + acc1;
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (lane < 16) slot[wave * 16 + lane] = v;
+            } else {
+                // lane holds D[row 4g+i][col r]; store as [col][row] so a pair reads 2 floats
+                *(kg_f4*)(slot + wave * 256 + r * 16 + g * 4) = acc;
+            }
+            __syncthreads();
+            const int n_epi = (MODE == MODE_VEC) ? 8 : 128;
+            if (tid < n_epi) {
+                const int m = tid >> 3, p = tid & 7;
+                if (m < M) {
+                    float v0 = 0.f, v1 = 0.f;
+                    for (int w = 0; w < nwaves; ++w) {
+                        const float* sp = slot + w * PART + m * 16 + 2 * p;
+                        v0 += sp[0]; v1 += sp[1];
+                    }
+                    epilogue_pair<DT, EPI>(a, rg * 16 + 2 * p, m, my_pos, v0, v1, run, side, it, M);
+                }
+            }
+            rg += gridDim.x; ct = t0; ++it;
+            acc = kg_f4{0.f, 0.f, 0.f, 0.f}; acc0 = 0.f; acc1 = 0.f;
+        }
+    };
+    // Steps come in pairs with a single back edge, so that at the top of the loop the other
+    // buffer's refill is always "newer" and the counted waits keep it in flight.  A trailing
+    // step past the last row group only sees out-of-range (zero) tiles and skips the epilogue.
+    do {
+        step(bufA, bufAx);
+        step(bufB, bufBx);
+    } while (rg < G);
     if (EPI == EPI_HEAD) {
         // merge the 8 pair-threads of each column, then one record per (block, column)
         const int n_epi = (MODE == MODE_VEC) ? 8 : 128;
@@ -317,21 +500,27 @@ size_t kg_linear_smem(int mfma, int max_rows, int K, int nwaves) {
 }
 
 // max_rows: upper bound of dyn->n_rows for this launch (sizes LDS); rows == 1 selects VEC.
-int kg_launch_linear(const KgLinArgs& a, int dtype, int max_rows, int pro, int epi, int nblocks, int nwaves, hipStream_t st) {
+int kg_launch_linear(const KgLinArgs& a_in, int dtype, int max_rows, int pro, int epi, int nblocks, int nwaves, hipStream_t st) {
+    KgLinArgs a = a_in;
     if (a.K % 32 != 0 || a.K <= 0 || a.N <= 0) return -1;
     if (max_rows < 1 || max_rows > KG_MAX_ROWS) return -1;
     if (nwaves < 1 || nwaves > 8) return -1;
     int mode = (max_rows == 1) ? MODE_VEC : MODE_MFMA;
-    size_t smem = kg_linear_smem(mode != MODE_VEC, max_rows, a.K, nwaves);
-    if (mode == MODE_MFMA) {
-        // X rows that would leave less than two blocks per CU (or not fit at all) are read
-        // as B fragments straight from global memory (L2) when no prologue has to rewrite them
-        if (pro == PRO_NONE && smem > 80 * 1024) { mode = MODE_MFMA_GX; smem = (size_t)2 * nwaves * 256 * 4; }
-        else if (smem > KG_LDS_LIMIT) return -3;
-    }
     const int G = (a.N + 15) / 16;
     if (nblocks > G) nblocks = G;
     if (nblocks < 1) nblocks = 1;
+    size_t side = 0;
+    if (epi == EPI_RESID) side = (size_t)((G + nblocks - 1) / nblocks) * max_rows * 16 * 2;
+    if (epi == EPI_ROPE_KV) side = (size_t)max_rows * a.head_dim * 4;
+    side = (side + 255) / 256 * 256;
+    a.side_bytes = (int)side;
+    size_t smem = side + kg_linear_smem(mode != MODE_VEC, max_rows, a.K, nwaves);
+    if (mode == MODE_MFMA) {
+        // X rows that would leave less than two blocks per CU (or not fit at all) are read
+        // as B fragments straight from global memory (L2) when no prologue has to rewrite them
+        if (pro == PRO_NONE && smem > 80 * 1024) { mode = MODE_MFMA_GX; smem = side + (size_t)2 * nwaves * 256 * 4; }
+        else if (smem > KG_LDS_LIMIT) return -3;
+    }
     dim3 grid(nblocks), block(nwaves * 64);
     int rc = (dtype == KG_F16) ? launch_dt<KG_F16>(a, mode, pro, epi, grid, block, smem, st)
                                : launch_dt<KG_BF16>(a, mode, pro, epi, grid, block, smem, st);

@@ -62,8 +62,7 @@ class EarlyExitLlamaForCausalLM:
         return self
 
     def _views(self, layer: int, length: int):
-        e = self.engine
-        return (e.k_cache[layer, :, :length, :].unsqueeze(0), e.v_cache[layer, :, :length, :].unsqueeze(0))
+        return self.engine.kv_views(layer, length)
 
     def _chunk_rows(self) -> int:
         d = self.engine.shape.hidden_size

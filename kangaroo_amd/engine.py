@@ -113,11 +113,17 @@ class KangarooEngine:
                           shape.intermediate_size, shape.vocab_size, shape.rms_norm_eps,
                           shape.max_position_embeddings, exit_layer)
         self._kshape = ks
-        t_max = max_length
+        t_max = (max_length + 31) // 32 * 32
+        # V is cached transposed ([.., hd, t_max]) when the MFMA attention kernel applies
+        self.v_transposed = hd >= 32
         self.k_cache = torch.zeros((shape.num_hidden_layers, Hkv, t_max, hd), dtype=dtype, device=dev)
-        self.v_cache = torch.zeros_like(self.k_cache)
         self.ak_cache = torch.zeros((Hkv, t_max, hd), dtype=dtype, device=dev)
-        self.av_cache = torch.zeros_like(self.ak_cache)
+        if self.v_transposed:
+            self.v_cache = torch.zeros((shape.num_hidden_layers, Hkv, hd, t_max), dtype=dtype, device=dev)
+            self.av_cache = torch.zeros((Hkv, hd, t_max), dtype=dtype, device=dev)
+        else:
+            self.v_cache = torch.zeros_like(self.k_cache)
+            self.av_cache = torch.zeros_like(self.ak_cache)
         wbytes = self.lib.kg_workspace_bytes(C.byref(ks), t_max)
         self.workspace = torch.zeros(wbytes, dtype=torch.uint8, device=dev)
         b = _lib.KgBuffers(self.k_cache.data_ptr(), self.v_cache.data_ptr(), self.ak_cache.data_ptr(), self.av_cache.data_ptr(),
@@ -126,6 +132,7 @@ class KangarooEngine:
         h = C.c_void_p(0)
         _lib.check(self.lib.kg_session_create(C.byref(ks), C.byref(w), C.byref(b), C.byref(h)), "kg_session_create")
         self._handle = h
+        assert self.lib.kg_session_get(h, b"v_transposed") == int(self.v_transposed)
         self.tokens = self._region("tokens", t_max * 4).view(torch.int32)
         self.hs_early = self._region("hs_early", t_max * shape.hidden_size * 2).view(dtype).view(t_max, shape.hidden_size)
 
@@ -136,6 +143,17 @@ class KangarooEngine:
             raise _lib.KangarooHipError(f"unknown workspace region {name}")
         off = p - self.workspace.data_ptr()
         return self.workspace[off:off + nbytes]
+
+    def kv_views(self, layer: int, length: int):
+        """(k, v) of one base layer as [1, Hkv, length, hd] views of the in-place caches."""
+        k = self.k_cache[layer, :, :length, :].unsqueeze(0)
+        v = self.v_cache[layer, :, :, :length].transpose(-1, -2) if self.v_transposed else self.v_cache[layer, :, :length, :]
+        return k, v.unsqueeze(0)
+
+    def adapter_kv_views(self, length: int):
+        k = self.ak_cache[:, :length, :].unsqueeze(0)
+        v = self.av_cache[:, :, :length].transpose(-1, -2) if self.v_transposed else self.av_cache[:, :length, :]
+        return k, v.unsqueeze(0)
 
     def close(self):
         if self._handle:

@@ -118,6 +118,10 @@ int main(int argc, char** argv) {
     if (what == "all" || what == "linear") {
         Shape shapes[] = {{"qkv", 12288, 4096}, {"o", 4096, 4096}, {"gateup", 22016, 4096}, {"down", 4096, 11008}, {"head", 32000, 4096}};
         int only_rows = argc > 2 ? atoi(argv[2]) : 0;
+        int force_pro = argc > 3 ? atoi(argv[3]) : -1;
+        int set_rows = argc > 4 ? atoi(argv[4]) : 7;
+        CK(kg_launch_set_dyn(dyn + 1, 1, set_rows, 0, st) == 0 ? hipSuccess : hipErrorUnknown);
+        CK(hipStreamSynchronize(st));
         for (auto& sh : shapes) {
             for (int rows : {1, 7}) {
                 if (only_rows && rows != only_rows) continue;
@@ -137,6 +141,7 @@ int main(int argc, char** argv) {
                                 a.W = pool + off; a.N = sh.N; a.K = sh.K; a.dyn = dyn + (rows == 1 ? 0 : 1); a.x = x; a.x_stride = sh.K;
                                 a.out = out; a.out_stride = sh.N; a.norm_w = nw; a.eps = 1e-6f;
                                 int pro = (sh.K == 4096 && strcmp(sh.name, "o") != 0) ? PRO_RMSNORM : PRO_NONE;
+                                if (force_pro >= 0) pro = force_pro;
                                 if (kg_launch_linear(a, KG_F16, rows, pro, EPI_STORE, nb, nw_, st) != 0) ok = false;
                                 off += bytes;
                             }

@@ -111,26 +111,28 @@ def test_qkv_rope_attention(dtype, code, H, Hkv, hd, rows, pos0):
     eye = torch.eye(H * hd)
     attn_ref, (k_ref, v_ref) = ko.attention(xn, pos, wq.float(), wk.float(), wv.float(), eye, (past_k.float(), past_v.float()) if pos0 else None,
                                             shape, tables, round_to=None)
+    vt = 1 if hd >= 32 else 0                     # transposed V cache + MFMA attention
     kc = torch.zeros((Hkv, t_max, hd), dtype=dtype, device=DEV)
-    vc = torch.zeros_like(kc)
+    vc = torch.zeros((Hkv, hd, t_max) if vt else (Hkv, t_max, hd), dtype=dtype, device=DEV)
+    vrows = (lambda n0, n1: vc[:, :, n0:n1].transpose(-1, -2)) if vt else (lambda n0, n1: vc[:, n0:n1])
     kc[:, :pos0] = past_k.to(DEV)
-    vc[:, :pos0] = past_v.to(DEV)
+    vrows(0, pos0).copy_(past_v.to(DEV))
     cos, sin = rope_tables(hd, 2048, device=DEV)
     q = torch.empty((rows, H * hd), dtype=dtype, device=DEV)
     scratch = torch.zeros(256, dtype=torch.uint8, device=DEV)
     wqkv_d, x_d, nw_d = pack_qkv(wq.to(DEV), wk.to(DEV), wv.to(DEV), H, Hkv, hd), x.to(DEV), nw.to(DEV)   # keep alive
     _lib.check(lib.kg_qkv_rope_append(code, vp(wqkv_d), d, H, Hkv, hd, vp(x_d), rows, pos0,
-                                      vp(nw_d), 1e-6, vp(cos), vp(sin), vp(q), vp(kc), vp(vc), t_max, vp(scratch), 0, 0, stream()),
+                                      vp(nw_d), 1e-6, vp(cos), vp(sin), vp(q), vp(kc), vp(vc), t_max, vt, vp(scratch), 0, 0, stream()),
                "kg_qkv_rope_append")
     torch.cuda.synchronize()
     tol = 6e-3 if dtype == torch.float16 else 3e-2
     assert rel_err(kc[:, :pos0 + rows], k_ref) < tol
-    assert rel_err(vc[:, :pos0 + rows], v_ref) < tol
+    assert rel_err(vrows(0, pos0 + rows), v_ref) < tol
     assert torch.equal(kc[:, :pos0].cpu(), past_k) and float(kc[:, pos0 + rows:].abs().max()) == 0.0   # only the new slots written
     for nsplit in (1, 4):
         ascr = torch.zeros(lib.kg_attention_scratch_bytes(H, hd, nsplit), dtype=torch.uint8, device=DEV)
         o = torch.full((rows, H * hd), float("nan"), dtype=dtype, device=DEV)
-        _lib.check(lib.kg_attention(code, vp(q), rows, pos0, vp(kc), vp(vc), H, Hkv, hd, t_max, nsplit, vp(o), vp(ascr), stream()), "kg_attention")
+        _lib.check(lib.kg_attention(code, vp(q), rows, pos0, vp(kc), vp(vc), H, Hkv, hd, t_max, vt, nsplit, vp(o), vp(ascr), stream()), "kg_attention")
         torch.cuda.synchronize()
         assert rel_err(o, attn_ref) < (1e-2 if dtype == torch.float16 else 5e-2), nsplit
 
