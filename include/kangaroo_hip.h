@@ -133,7 +133,11 @@ int kg_session_destroy(kg_session* s);
 /* kg_session_get: "v_transposed" (layout of buffers.v_cache / av_cache the session expects:
  * 1 when head_dim >= 32 and t_max % 32 == 0), "prefill_rows", or a tuning key; -1 if unknown. */
 int kg_session_get(kg_session* s, const char* key);
-/* tuning knobs: key in {"vec_blocks_per_cu","mfma_blocks_per_cu","vec_waves","mfma_waves","attn_nsplit"} */
+/* tuning knobs (launch geometry; results do not depend on them except "attn_nsplit", which fixes
+ * the split boundaries of the attention reduction): "attn_nsplit"; "<mode>_waves" and
+ * "<mode>_blocks_per_cu" for all linear ops of a mode, or "<mode>.<op>.waves" /
+ * "<mode>.<op>.blocks_per_cu" for one, with mode in {vec (1 row), mfma (2..16 rows)} and op in
+ * {qkv, o, gateup, down, head}.  kg_session_get reads the per-op keys back. */
 int kg_session_set(kg_session* s, const char* key, int value);
 
 /* Device address of a named region of the workspace ("tokens": int32[t_max], "state":

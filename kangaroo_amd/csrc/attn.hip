@@ -37,6 +37,8 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_kernel(const KgAttnArgs a
     // together with later rows, which keeps verify and plain decoding bit-identical.
     int chunk = (a.t_max + nsplit - 1) / nsplit;
     chunk = (chunk + BR - 1) / BR * BR;
+    const int n_act = (len + chunk - 1) / chunk;   // splits that hold keys; the others do nothing
+    if (split >= n_act) return;
     const int tbeg = split * chunk, tend = min(len, tbeg + chunk);
 
     // query fragments (this lane's 8 dims of every row) and causal limits
@@ -153,7 +155,7 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_kernel(const KgAttnArgs a
             l += f * s_ml[w][m][1];
         }
         const int mm = m0 + m;
-        if (nsplit == 1) {
+        if (n_act == 1) {
             ((unsigned short*)a.out)[(size_t)mm * a.H * hd + (size_t)h * hd + dmi] = T::from_f(o / l);
         } else {
             a.part_o[(((size_t)split * a.max_rows + mm) * a.H + h) * hd + dmi] = o;
@@ -192,6 +194,8 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnA
     constexpr int DB = HD / 16;                    // 16-wide head-dim blocks of the output
     int chunk = (a.t_max + nsplit - 1) / nsplit;   // fixed split boundaries (see kg_attn_kernel)
     chunk = (chunk + 31) / 32 * 32;
+    const int n_act = (len + chunk - 1) / chunk;   // splits that hold keys; the others do nothing
+    if (split >= n_act) return;
     const int tbeg = split * chunk, tend = min(len, tbeg + chunk);
     const int lim = (c < M) ? pos_c : -1;          // causal bound of this lane's query column
 
@@ -290,7 +294,7 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnA
             o += fw * s_o[w][m][dmi];
             l += fw * s_ml[w][m][1];
         }
-        if (nsplit == 1) {
+        if (n_act == 1) {
             ((unsigned short*)a.out)[((size_t)m * a.H + h) * HD + dmi] = T::from_f(o / l);
         } else {
             a.part_o[(((size_t)split * a.max_rows + m) * a.H + h) * HD + dmi] = o;
@@ -311,7 +315,12 @@ __global__ void kg_attn_combine_kernel(const KgAttnArgs a) {
     const int M = dyn->n_rows;
     const int h = blockIdx.x, m = blockIdx.y;
     if (m >= M) return;
-    const int hd = a.hd, ns = a.nsplit;
+    const int hd = a.hd;
+    const int len = dyn->pos[M - 1] + 1;
+    int chunk = (a.t_max + a.nsplit - 1) / a.nsplit;
+    chunk = (chunk + a.chunk_round - 1) / a.chunk_round * a.chunk_round;
+    const int ns = (len + chunk - 1) / chunk;          // active splits, as the attention kernel counts them
+    if (ns == 1) return;                               // the single split wrote the final rows itself
     float mx = -INFINITY;
     for (int s = 0; s < ns; ++s) mx = fmaxf(mx, a.part_ml[(((size_t)s * a.max_rows + m) * a.H + h) * 2]);
     for (int dmi = threadIdx.x; dmi < hd; dmi += blockDim.x) {
@@ -356,8 +365,10 @@ static int launch_dt(const KgAttnArgs& a, hipStream_t st) {
         }
     }
     if (a.nsplit > 1) {
+        KgAttnArgs c = a;
+        c.chunk_round = a.v_transposed ? 32 : ATT_U * (64 / (a.hd / 8));     // rows per batch of the kernel that ran
         dim3 grid(a.H, a.max_rows);
-        hipLaunchKernelGGL((kg_attn_combine_kernel<DT>), grid, dim3(a.hd < 64 ? 64 : a.hd), 0, st, a);
+        hipLaunchKernelGGL((kg_attn_combine_kernel<DT>), grid, dim3(a.hd < 64 ? 64 : a.hd), 0, st, c);
     }
     return 0;
 }

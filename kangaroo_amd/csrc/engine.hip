@@ -45,7 +45,9 @@ struct kg_session {
     int head_part_stride;
     int prefill_rows;
     // tuning
-    int vec_bpc, mfma_bpc, vec_waves, mfma_waves, attn_nsplit;
+    // launch geometry per (mode: 0 GEMV / 1 MFMA, op: qkv, o, gateup, down, head)
+    int waves[2][5], bpc[2][5];
+    int attn_nsplit;
     int v_transposed;
     // graphs
     hipStream_t own_stream;
@@ -128,7 +130,9 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     Carver c{(char*)buffers->workspace, 0};
     carve(s, c, shape, buffers->t_max);
     s->prefill_rows = prefill_rows_for(shape);
-    s->vec_bpc = 2; s->mfma_bpc = 1; s->vec_waves = 8; s->mfma_waves = 8;
+    for (int op = 0; op < 5; ++op) { s->waves[0][op] = 8; s->bpc[0][op] = 2; s->waves[1][op] = 8; s->bpc[1][op] = 1; }
+    s->waves[0][1] = 4; s->waves[0][3] = 4;      // o_proj, down_proj: one row group per block, 4 waves measured best
+    s->waves[1][3] = 2;                          // down_proj in the large-K MFMA mode
     s->v_transposed = (shape->head_dim >= 32 && buffers->t_max % 32 == 0) ? 1 : 0;
     s->attn_nsplit = 16;
     s->round_graph = nullptr; s->round_graph_steps = -1; s->vanilla_graph = nullptr;
@@ -155,16 +159,25 @@ extern "C" int kg_session_destroy(kg_session* s) {
     return 0;
 }
 
+static const char* kg_op_names[5] = {"qkv", "o", "gateup", "down", "head"};
+enum { OP_QKV = 0, OP_O = 1, OP_GATEUP = 2, OP_DOWN = 3, OP_HEAD = 4 };
+
 extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
     if (!s || !key) return fail(-1, "null argument");
     std::string k(key);
     if (value < 1) return fail(-1, "value must be >= 1");
-    if (k == "vec_blocks_per_cu") s->vec_bpc = value;
-    else if (k == "mfma_blocks_per_cu") s->mfma_bpc = value;
-    else if (k == "vec_waves") { if (value > 8) return fail(-1, "waves <= 8"); s->vec_waves = value; }
-    else if (k == "mfma_waves") { if (value > 8) return fail(-1, "waves <= 8"); s->mfma_waves = value; }
-    else if (k == "attn_nsplit") { if (value > 32) return fail(-1, "nsplit <= 32"); s->attn_nsplit = value; }
-    else return fail(-1, "unknown key");
+    bool done = false;
+    if (k == "attn_nsplit") { if (value > 32) return fail(-1, "nsplit <= 32"); s->attn_nsplit = value; done = true; }
+    for (int mode = 0; mode < 2 && !done; ++mode) {
+        const std::string mname = mode == 0 ? "vec" : "mfma";
+        if (k == mname + "_waves") { if (value > 8) return fail(-1, "waves <= 8"); for (int op = 0; op < 5; ++op) s->waves[mode][op] = value; done = true; }
+        if (k == mname + "_blocks_per_cu") { for (int op = 0; op < 5; ++op) s->bpc[mode][op] = value; done = true; }
+        for (int op = 0; op < 5 && !done; ++op) {
+            if (k == mname + "." + kg_op_names[op] + ".waves") { if (value > 8) return fail(-1, "waves <= 8"); s->waves[mode][op] = value; done = true; }
+            if (k == mname + "." + kg_op_names[op] + ".blocks_per_cu") { s->bpc[mode][op] = value; done = true; }
+        }
+    }
+    if (!done) return fail(-1, "unknown key");
     // graphs bake the launch geometry in
     if (s->round_graph) { hipGraphExecDestroy(s->round_graph); s->round_graph = nullptr; s->round_graph_steps = -1; }
     if (s->vanilla_graph) { hipGraphExecDestroy(s->vanilla_graph); s->vanilla_graph = nullptr; }
@@ -175,10 +188,13 @@ extern "C" int kg_session_get(kg_session* s, const char* key) {
     if (!s || !key) return -1;
     std::string k(key);
     if (k == "v_transposed") return s->v_transposed;
-    if (k == "vec_blocks_per_cu") return s->vec_bpc;
-    if (k == "mfma_blocks_per_cu") return s->mfma_bpc;
-    if (k == "vec_waves") return s->vec_waves;
-    if (k == "mfma_waves") return s->mfma_waves;
+    for (int mode = 0; mode < 2; ++mode) {
+        const std::string mname = mode == 0 ? "vec" : "mfma";
+        for (int op = 0; op < 5; ++op) {
+            if (k == mname + "." + kg_op_names[op] + ".waves") return s->waves[mode][op];
+            if (k == mname + "." + kg_op_names[op] + ".blocks_per_cu") return s->bpc[mode][op];
+        }
+    }
     if (k == "attn_nsplit") return s->attn_nsplit;
     if (k == "prefill_rows") return s->prefill_rows;
     return -1;
@@ -198,13 +214,12 @@ extern "C" void* kg_session_ptr(kg_session* s, const char* name) {
 // ---------------------------------------------------------------------------------
 // pass composition
 // ---------------------------------------------------------------------------------
-static int grid_for(const kg_session* s, int N, int max_rows) {
+static int grid_for(const kg_session* s, int N, int max_rows, int op) {
     const int G = (N + 15) / 16;
-    const int per = (max_rows == 1) ? s->vec_bpc : s->mfma_bpc;
-    int nb = g_ncu * per;
+    const int nb = g_ncu * s->bpc[max_rows == 1 ? 0 : 1][op];
     return nb < G ? nb : G;
 }
-static int waves_for(const kg_session* s, int max_rows) { return max_rows == 1 ? s->vec_waves : s->mfma_waves; }
+static int waves_for(const kg_session* s, int max_rows, int op) { return s->waves[max_rows == 1 ? 0 : 1][op]; }
 
 static KgLinArgs lin_base(const KgDyn* dyn, const void* W, int N, int K, const void* x, int x_stride) {
     KgLinArgs a;
@@ -219,14 +234,13 @@ static int run_layer(kg_session* s, const kg_layer_weights& lw, void* kc, void* 
                      const void* h_in, void* h_out, hipStream_t st) {
     const kg_shape& sh = s->sh;
     const int d = sh.hidden_size, F = sh.intermediate_size, dt = sh.dtype;
-    const int nw = waves_for(s, max_rows);
     {
         KgLinArgs a = lin_base(dyn, lw.wqkv, s->q_dim + 2 * s->kv_dim, d, h_in, d);
         a.norm_w = lw.norm1; a.eps = sh.rms_eps;
         a.q_out = s->xq; a.k_cache = kc; a.v_cache = vc;
         a.rope_cos = s->w.rope_cos; a.rope_sin = s->w.rope_sin;
         a.head_dim = sh.head_dim; a.q_dim = s->q_dim; a.kv_dim = s->kv_dim; a.t_max = s->buf.t_max; a.v_transposed = s->v_transposed;
-        KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_RMSNORM, EPI_ROPE_KV, grid_for(s, a.N, max_rows), nw, st));
+        KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_RMSNORM, EPI_ROPE_KV, grid_for(s, a.N, max_rows, OP_QKV), waves_for(s, max_rows, OP_QKV), st));
     }
     {
         KgAttnArgs a;
@@ -241,19 +255,19 @@ static int run_layer(kg_session* s, const kg_layer_weights& lw, void* kc, void* 
     {
         KgLinArgs a = lin_base(dyn, lw.wo, d, s->q_dim, s->attn_out, s->q_dim);
         a.out = h_mid; a.out_stride = d; a.resid = h_in; a.resid_stride = d;
-        KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_NONE, EPI_RESID, grid_for(s, a.N, max_rows), nw, st));
+        KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_NONE, EPI_RESID, grid_for(s, a.N, max_rows, OP_O), waves_for(s, max_rows, OP_O), st));
     }
     if (attn_only) return 0;
     {
         KgLinArgs a = lin_base(dyn, lw.wgu, 2 * F, d, h_mid, d);
         a.norm_w = lw.norm2; a.eps = sh.rms_eps;
         a.out = s->act; a.out_stride = F;
-        KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_RMSNORM, EPI_SILU_MUL, grid_for(s, a.N, max_rows), nw, st));
+        KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_RMSNORM, EPI_SILU_MUL, grid_for(s, a.N, max_rows, OP_GATEUP), waves_for(s, max_rows, OP_GATEUP), st));
     }
     {
         KgLinArgs a = lin_base(dyn, lw.wdown, d, F, s->act, F);
         a.out = h_out; a.out_stride = d; a.resid = h_mid; a.resid_stride = d;
-        KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_NONE, EPI_RESID, grid_for(s, a.N, max_rows), nw, st));
+        KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_NONE, EPI_RESID, grid_for(s, a.N, max_rows, OP_DOWN), waves_for(s, max_rows, OP_DOWN), st));
     }
     return 0;
 }
@@ -270,9 +284,9 @@ static int run_head(kg_session* s, const KgDyn* dyn, int max_rows, const void* x
     a.norm_w = norm_w; a.eps = s->sh.rms_eps;
     a.head_part = s->head_part; a.head_part_stride = s->head_part_stride;
     a.logits_out = logits_out; a.logits_stride = s->sh.vocab_size;
-    int nb = grid_for(s, a.N, max_rows);
+    int nb = grid_for(s, a.N, max_rows, OP_HEAD);
     *nblocks = nb;
-    return kg_launch_linear(a, s->sh.dtype, max_rows, norm_w ? PRO_RMSNORM : PRO_NONE, EPI_HEAD, nb, waves_for(s, max_rows), st);
+    return kg_launch_linear(a, s->sh.dtype, max_rows, norm_w ? PRO_RMSNORM : PRO_NONE, EPI_HEAD, nb, waves_for(s, max_rows, OP_HEAD), st);
 }
 
 static KgLoopBufs loop_bufs(kg_session* s) {
@@ -305,7 +319,7 @@ extern "C" int kg_forward_layers(kg_session* s, int layer_begin, int layer_end, 
     if (pos0 < 0 || pos0 + n_rows > s->buf.t_max) return fail(-1, "positions exceed the cache");
     const int d = s->sh.hidden_size;
     const int max_rows = (n_rows == 1) ? 1 : n_rows;
-    if (max_rows > 1 && kg_linear_smem(1, max_rows, d, s->mfma_waves) > 160 * 1024) return fail(-3, "rows x hidden_size exceed LDS; use fewer rows per call");
+    if (max_rows > 1 && kg_linear_smem(1, max_rows, d, 8) > 160 * 1024) return fail(-3, "rows x hidden_size exceed LDS; use fewer rows per call");
     KG_TRY(kg_launch_set_dyn(s->dyn_call, 1, n_rows, pos0, st));
     const void* cur = x_in;
     if (!x_in) {
@@ -336,7 +350,7 @@ extern "C" int kg_adapter_forward(kg_session* s, const void* x_in, int pos0, int
     if (pos0 < 0 || pos0 + n_rows > s->buf.t_max) return fail(-1, "positions exceed the cache");
     const int d = s->sh.hidden_size;
     const int max_rows = (n_rows == 1) ? 1 : n_rows;
-    if (max_rows > 1 && kg_linear_smem(1, max_rows, d, s->mfma_waves) > 160 * 1024) return fail(-3, "rows x hidden_size exceed LDS; use fewer rows per call");
+    if (max_rows > 1 && kg_linear_smem(1, max_rows, d, 8) > 160 * 1024) return fail(-3, "rows x hidden_size exceed LDS; use fewer rows per call");
     KG_TRY(kg_launch_set_dyn(s->dyn_call, 1, n_rows, pos0, st));
     KG_TRY(run_layer(s, s->w.adapter, s->buf.ak_cache, s->buf.av_cache, s->dyn_call, max_rows, x_in, s->adapter_h, st));
     return kg_launch_rmsnorm(s->dyn_call, s->adapter_h, d, s->w.adapter_norm, s->sh.rms_eps, d, h_out, d, s->sh.dtype, st);
@@ -571,7 +585,6 @@ extern "C" int kg_bench_op(kg_session* s, int op, int rows, int iters, float* us
     hipStream_t st = s->own_stream;
     const kg_shape& sh = s->sh;
     const int d = sh.hidden_size, F = sh.intermediate_size, dt = sh.dtype, N = sh.num_layers;
-    const int nw = waves_for(s, rows);
     KG_TRY(kg_launch_set_dyn(s->dyn_call, 1, rows, 0, st));
     KG_CHECK_HIP(hipStreamSynchronize(st));
     hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
@@ -585,22 +598,22 @@ extern "C" int kg_bench_op(kg_session* s, int op, int rows, int iters, float* us
             a.norm_w = lw.norm1; a.eps = sh.rms_eps; a.q_out = s->xq; a.k_cache = layer_k(s, i % N); a.v_cache = layer_v(s, i % N);
             a.rope_cos = s->w.rope_cos; a.rope_sin = s->w.rope_sin; a.head_dim = sh.head_dim; a.q_dim = s->q_dim; a.kv_dim = s->kv_dim; a.t_max = s->buf.t_max; a.v_transposed = s->v_transposed;
             wbytes = (size_t)a.N * d * 2;
-            rc = kg_launch_linear(a, dt, rows, PRO_RMSNORM, EPI_ROPE_KV, grid_for(s, a.N, rows), nw, st);
+            rc = kg_launch_linear(a, dt, rows, PRO_RMSNORM, EPI_ROPE_KV, grid_for(s, a.N, rows, OP_QKV), waves_for(s, rows, OP_QKV), st);
         } else if (op == 1) {
             KgLinArgs a = lin_base(s->dyn_call, lw.wo, d, s->q_dim, s->attn_out, s->q_dim);
             a.out = s->h2; a.out_stride = d; a.resid = s->h; a.resid_stride = d;
             wbytes = (size_t)d * s->q_dim * 2;
-            rc = kg_launch_linear(a, dt, rows, PRO_NONE, EPI_RESID, grid_for(s, a.N, rows), nw, st);
+            rc = kg_launch_linear(a, dt, rows, PRO_NONE, EPI_RESID, grid_for(s, a.N, rows, OP_O), waves_for(s, rows, OP_O), st);
         } else if (op == 2) {
             KgLinArgs a = lin_base(s->dyn_call, lw.wgu, 2 * F, d, s->h, d);
             a.norm_w = lw.norm2; a.eps = sh.rms_eps; a.out = s->act; a.out_stride = F;
             wbytes = (size_t)2 * F * d * 2;
-            rc = kg_launch_linear(a, dt, rows, PRO_RMSNORM, EPI_SILU_MUL, grid_for(s, a.N, rows), nw, st);
+            rc = kg_launch_linear(a, dt, rows, PRO_RMSNORM, EPI_SILU_MUL, grid_for(s, a.N, rows, OP_GATEUP), waves_for(s, rows, OP_GATEUP), st);
         } else if (op == 3) {
             KgLinArgs a = lin_base(s->dyn_call, lw.wdown, d, F, s->act, F);
             a.out = s->h2; a.out_stride = d; a.resid = s->h; a.resid_stride = d;
             wbytes = (size_t)d * F * 2;
-            rc = kg_launch_linear(a, dt, rows, PRO_NONE, EPI_RESID, grid_for(s, a.N, rows), nw, st);
+            rc = kg_launch_linear(a, dt, rows, PRO_NONE, EPI_RESID, grid_for(s, a.N, rows, OP_DOWN), waves_for(s, rows, OP_DOWN), st);
         } else {
             int nb = 0;
             wbytes = (size_t)sh.vocab_size * d * 2;

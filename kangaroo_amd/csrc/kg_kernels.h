@@ -24,6 +24,7 @@ struct KgLinArgs {
     // EPI_HEAD
     float* head_part; int head_part_stride;         // [rows][head_part_stride][4]
     void* logits_out; int logits_stride;            // optional
+    int gx_slot_rows;                               // set by the launcher: rows of a wave's X slot (large-K MFMA mode)
     int side_bytes;                                 // set by the launcher: LDS bytes of staged epilogue inputs
 };
 
@@ -43,6 +44,7 @@ struct KgAttnArgs {
     float* part_ml;             // [nsplit][rows][H][2]
     void* out;                  // [n_rows, H*hd]
     int max_rows;
+    int chunk_round;            // set by the launcher for the combine kernel
 };
 int kg_launch_attn(const KgAttnArgs& a, int dtype, hipStream_t st);
 

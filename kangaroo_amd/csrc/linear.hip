@@ -19,8 +19,11 @@
 #include "kg_common.h"
 #include "kg_kernels.h"
 
-#ifndef KG_U
-#define KG_U 8          // weight tiles (KiB) per wave kept in flight per batch
+#ifndef KG_U_VEC
+#define KG_U_VEC 8      // weight tiles (KiB) per batch and wave; two batches are in flight
+#endif
+#ifndef KG_U_MFMA
+#define KG_U_MFMA 8
 #endif
 
 enum { MODE_VEC = 0, MODE_MFMA = 1, MODE_MFMA_GX = 2 };
@@ -126,51 +129,37 @@ __device__ __forceinline__ void epilogue_pair(const KgLinArgs& a, int n0, int m,
 // keeps them in registers; prologue_finish runs after the weight loads are in flight, so
 // the norm and the LDS fill overlap the first HBM round trip (the memory counter retires
 // in order: x requested first is waited for with the weight loads still outstanding).
+// RMSNorm is applied in two halves: the prologue stores gamma[k] * x[m][k] (rounded to the
+// model dtype) and every thread keeps the sum of squares of the chunks it touched; the row
+// factor rsqrt(mean(x^2) + eps) multiplies the finished dot products in the epilogue, after
+// the partial sums of squares have met in LDS at the first row group's barrier.  The norm
+// therefore costs no barrier and no reduction before the weight stream starts.
 template <int RM> struct ProRegs { kg_u4 v[RM]; kg_u4 gw; };
 
 template <int DT, int PRO, int RM>
-__device__ __forceinline__ void prologue_slow(const KgLinArgs& a, char* xs, int xs_stride, float* red, int M, int row_off,
+__device__ __forceinline__ void prologue_slow(const KgLinArgs& a, char* xs, int xs_stride, float (&ss)[RM], int M, int row_off,
                                               int tid, int nthreads) {
     typedef KgT<DT> T;
-    const int K = a.K, nchunk = K >> 3;
-    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    const int nchunk = a.K >> 3;
     const kg_u4* wn = (const kg_u4*)a.norm_w;
-    if (PRO == PRO_NONE) {
-        for (int m = 0; m < M; ++m) {
+#pragma unroll
+    for (int m = 0; m < RM; ++m) {
+        if (m < M) {
             const kg_u4* src = (const kg_u4*)((const unsigned short*)a.x + (size_t)(m + row_off) * a.x_stride);
             kg_u4* dst = (kg_u4*)(xs + (size_t)m * xs_stride);
-            for (int c = tid; c < nchunk; c += nthreads) dst[c] = src[c];
-        }
-        return;
-    }
-    for (int m = 0; m < M; ++m) {
-        const kg_u4* src = (const kg_u4*)((const unsigned short*)a.x + (size_t)(m + row_off) * a.x_stride);
-        float ss = 0.f;
-        for (int c = tid; c < nchunk; c += nthreads) {
-            kg_us8 h = __builtin_bit_cast(kg_us8, src[c]);
+            for (int c = tid; c < nchunk; c += nthreads) {
+                if (PRO == PRO_NONE) { dst[c] = src[c]; continue; }
+                kg_us8 h = __builtin_bit_cast(kg_us8, src[c]);
+                kg_us8 g = __builtin_bit_cast(kg_us8, wn[c]);
+                kg_us8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { float f = T::to_f(h[j]); ss += f * f; }
-        }
-        ss = kg_wave_sum(ss);
-        if (lane == 0) red[m * nwaves + wave] = ss;
-    }
-    __syncthreads();
-    for (int m = 0; m < M; ++m) {
-        float tot = 0.f;
-        for (int w = 0; w < nwaves; ++w) tot += red[m * nwaves + w];
-        const float rstd = rsqrtf(tot / (float)K + a.eps);
-        const kg_u4* src = (const kg_u4*)((const unsigned short*)a.x + (size_t)(m + row_off) * a.x_stride);
-        kg_u4* dst = (kg_u4*)(xs + (size_t)m * xs_stride);
-        for (int c = tid; c < nchunk; c += nthreads) {
-            kg_us8 h = __builtin_bit_cast(kg_us8, src[c]);
-            kg_us8 g = __builtin_bit_cast(kg_us8, wn[c]);
-            kg_us8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float f = kg_round<DT>(T::to_f(h[j]) * rstd);
-                o[j] = T::from_f(T::to_f(g[j]) * f);
+                for (int j = 0; j < 8; ++j) {
+                    const float f = T::to_f(h[j]);
+                    ss[m] += f * f;
+                    o[j] = T::from_f(T::to_f(g[j]) * f);
+                }
+                dst[c] = __builtin_bit_cast(kg_u4, o);
             }
-            dst[c] = __builtin_bit_cast(kg_u4, o);
         }
     }
 }
@@ -193,45 +182,27 @@ __device__ __forceinline__ void prologue_load(const KgLinArgs& a, ProRegs<RM>& p
 }
 
 template <int DT, int PRO, int RM>
-__device__ __forceinline__ void prologue_finish(const KgLinArgs& a, const ProRegs<RM>& pr, char* xs, int xs_stride, float* red, int M,
-                                                int tid, int nthreads) {
+__device__ __forceinline__ void prologue_finish(const KgLinArgs& a, const ProRegs<RM>& pr, char* xs, int xs_stride, float (&ss)[RM], int M,
+                                                int tid) {
     typedef KgT<DT> T;
-    const int K = a.K, nchunk = K >> 3;
-    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
-    if (PRO == PRO_NONE) {
-#pragma unroll
-        for (int m = 0; m < RM; ++m)
-            if (m < M && tid < nchunk) *(kg_u4*)(xs + (size_t)m * xs_stride + tid * 16) = pr.v[m];
-        return;
-    }
-#pragma unroll
-    for (int m = 0; m < RM; ++m) {
-        if (m < M) {
-            kg_us8 h = __builtin_bit_cast(kg_us8, pr.v[m]);
-            float ss = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { float f = T::to_f(h[j]); ss += f * f; }
-            ss = kg_wave_sum(ss);
-            if (lane == 0) red[m * nwaves + wave] = ss;
-        }
-    }
-    __syncthreads();
+    const int nchunk = a.K >> 3;
     kg_us8 g = __builtin_bit_cast(kg_us8, pr.gw);
 #pragma unroll
     for (int m = 0; m < RM; ++m) {
-        if (m < M) {
-            float tot = 0.f;
-            for (int w = 0; w < nwaves; ++w) tot += red[m * nwaves + w];
-            const float rstd = rsqrtf(tot / (float)K + a.eps);
-            kg_us8 h = __builtin_bit_cast(kg_us8, pr.v[m]);
-            kg_us8 o;
+        if (m < M && tid < nchunk) {
+            if (PRO == PRO_NONE) {
+                *(kg_u4*)(xs + (size_t)m * xs_stride + tid * 16) = pr.v[m];
+            } else {
+                kg_us8 h = __builtin_bit_cast(kg_us8, pr.v[m]);
+                kg_us8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                // normalise in fp32, store in the model dtype, then scale by the weight
-                float f = kg_round<DT>(T::to_f(h[j]) * rstd);
-                o[j] = T::from_f(T::to_f(g[j]) * f);
+                for (int j = 0; j < 8; ++j) {
+                    const float f = T::to_f(h[j]);
+                    ss[m] += f * f;
+                    o[j] = T::from_f(T::to_f(g[j]) * f);
+                }
+                *(kg_u4*)(xs + (size_t)m * xs_stride + tid * 16) = __builtin_bit_cast(kg_u4, o);
             }
-            if (tid < nchunk) *(kg_u4*)(xs + (size_t)m * xs_stride + tid * 16) = __builtin_bit_cast(kg_u4, o);
         }
     }
 }
@@ -250,8 +221,12 @@ __global__ void __launch_bounds__(512) kg_linear_kernel(const KgLinArgs a) {
     const int M = (MODE == MODE_VEC) ? 1 : n_rows;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RM = (MODE == MODE_VEC) ? 1 : KG_MAX_ROWS;
+    constexpr int KG_U = (MODE == MODE_MFMA) ? KG_U_MFMA : KG_U_VEC;
+    constexpr int GX_ROW = 8 * 64 + 16;                           // bytes of one X row of a batch in a wave's LDS slot (+ pad)
+    static_assert(MODE != MODE_MFMA_GX || KG_U == 8, "the X slot layout assumes 8 tiles per batch");
     const int PART = (MODE == MODE_VEC) ? 16 : 256;            // floats per wave partial
     char* side = smem;                                           // epilogue inputs staged once (residual rows / RoPE rows)
+    float* red2 = (float*)(smem + a.side_bytes - 512);           // [rows][nwaves] partial sums of squares (last 512 B of the side region)
     float* part = (float*)(smem + a.side_bytes);                 // [2][nwaves][PART]
     char* xs = smem + a.side_bytes + 2 * nwaves * PART * 4;
     const int my_pos = (EPI == EPI_ROPE_KV) ? __shfl(posv, (tid >> 3) & (KG_MAX_ROWS - 1), 64) : 0;
@@ -273,9 +248,12 @@ __global__ void __launch_bounds__(512) kg_linear_kernel(const KgLinArgs a) {
     const int row_off = (MODE == MODE_VEC && a.x_last_row) ? n_rows - 1 : 0;
     const bool pro_fast = (a.K >> 3) <= nthreads;
     ProRegs<RM> pr;
+    float ss[RM];                                                // this thread's share of sum(x^2) per row
+#pragma unroll
+    for (int m = 0; m < RM; ++m) ss[m] = 0.f;
     if (MODE != MODE_MFMA_GX) {
         if (pro_fast) prologue_load<PRO, RM>(a, pr, M, row_off, tid);
-        else prologue_slow<DT, PRO, RM>(a, xs, xs_stride, part, M, row_off, tid, nthreads);
+        else prologue_slow<DT, PRO, RM>(a, xs, xs_stride, ss, M, row_off, tid, nthreads);
     }
     unsigned side_raw[2] = {0u, 0u};
     const int nrg_blk = (G - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -339,18 +317,26 @@ __global__ void __launch_bounds__(512) kg_linear_kernel(const KgLinArgs a) {
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (int)((size_t)G * KT * 1024), 0x00020000);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0,
         (MODE == MODE_MFMA_GX) ? (int)(((size_t)(M - 1) * a.x_stride + a.K) * 2) : 0, 0x00020000);
-    const unsigned xoff0 = (unsigned)(((size_t)mrow * a.x_stride) * 2 + g * 16);
+    // MODE_MFMA_GX (X too large for LDS as a whole): each wave moves the X columns of its next
+    // batch (rows x 8 tiles x 64 B, row-contiguous 512-byte pieces) through a wave-private LDS
+    // slot.  The X loads are issued ahead of the batch's weight tiles, so waiting for them
+    // never waits for those weights (the counter retires in order).
     auto issue = [&](kg_u4 (&wv)[KG_U], kg_u4 (&xv)[KG_U], int lrg, int lt) {
+        if (MODE == MODE_MFMA_GX) {
+#pragma unroll
+            for (int j = 0; j < KG_U; ++j) {
+                const int flat = j * 64 + lane, row = flat >> 5, ch = flat & 31;
+                const bool okx = (lrg < G) && (row < M) && (lt + (ch >> 2) < t1);
+                const unsigned xo = okx ? (unsigned)(((size_t)row * a.x_stride) * 2) + (unsigned)lt * 64u + (unsigned)ch * 16u : 0xFFFFFFFFu;
+                xv[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo, 0, 0);
+            }
+        }
         const unsigned base = (unsigned)lrg * (unsigned)KT * 1024u + (unsigned)lane * 16u;
 #pragma unroll
         for (int u = 0; u < KG_U; ++u) {
             const bool ok = (lrg < G) && (lt + u < t1);
             const unsigned off = ok ? base + (unsigned)(lt + u) * 1024u : 0xFFFFFFFFu;
             wv[u] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 2);
-            if (MODE == MODE_MFMA_GX) {
-                const unsigned xo = ok ? xoff0 + (unsigned)(lt + u) * 64u : 0xFFFFFFFFu;
-                xv[u] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo, 0, 0);
-            }
         }
     };
 
@@ -373,10 +359,11 @@ __global__ void __launch_bounds__(512) kg_linear_kernel(const KgLinArgs a) {
             }
         }
     }
-    if (MODE != MODE_MFMA_GX && pro_fast) prologue_finish<DT, PRO, RM>(a, pr, xs, xs_stride, part, M, tid, nthreads);
+    if (MODE != MODE_MFMA_GX && pro_fast) prologue_finish<DT, PRO, RM>(a, pr, xs, xs_stride, ss, M, tid);
     __syncthreads();
 
     HeadRun run; run.mx = -INFINITY; run.sum = 0.f; run.idx = 0;
+    float rstd = 1.f;
     int it = 0, ct = t0;
     kg_f4 acc = {0.f, 0.f, 0.f, 0.f};
     float acc0 = 0.f, acc1 = 0.f;
@@ -385,7 +372,15 @@ __global__ void __launch_bounds__(512) kg_linear_kernel(const KgLinArgs a) {
     // two ahead (the two buffers alternate, so no register copies and up to 2*KG_U tiles stay
     // in flight per wave), and at the end of a row group reduce across waves and run the
     // epilogue.
-    auto step = [&](kg_u4 (&wv)[KG_U], kg_u4 (&xv)[KG_U]) {
+    auto step = [&](kg_u4 (&wv)[KG_U], kg_u4 (&xv)[KG_U], int which) {
+        char* xslot = xs + (size_t)(wave * 2 + which) * a.gx_slot_rows * GX_ROW;      // MODE_MFMA_GX only
+        if (MODE == MODE_MFMA_GX) {
+#pragma unroll
+            for (int j = 0; j < KG_U; ++j) {
+                const int flat = j * 64 + lane, row = flat >> 5, ch = flat & 31;
+                if (row < a.gx_slot_rows) *(kg_u4*)(xslot + row * GX_ROW + ch * 16) = xv[j];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < KG_U; ++u) {
             const kg_u4 w = wv[u];                    // zeros when the tile was out of range
@@ -400,7 +395,8 @@ __global__ void __launch_bounds__(512) kg_linear_kernel(const KgLinArgs a) {
                 kg_u4 x = *(const kg_u4*)(xl + (size_t)tt * 64);
                 acc = T::mfma(w, x, acc);
             } else {
-                acc = T::mfma(w, xv[u], acc);
+                kg_u4 x = *(const kg_u4*)(xslot + mrow * GX_ROW + u * 64 + g * 16);
+                acc = T::mfma(w, x, acc);
             }
         }
         issue(wv, xv, lrg, lt);
@@ -419,16 +415,31 @@ __global__ void __launch_bounds__(512) kg_linear_kernel(const KgLinArgs a) {
                 // lane holds D[row 4g+i][col r]; store as [col][row] so a pair reads 2 floats
                 *(kg_f4*)(slot + wave * 256 + r * 16 + g * 4) = acc;
             }
+            if (PRO == PRO_RMSNORM && it == 0) {
+#pragma unroll
+                for (int m = 0; m < RM; ++m) {
+                    if (m < M) {
+                        const float t = kg_wave_sum(ss[m]);
+                        if (lane == 0) red2[m * nwaves + wave] = t;
+                    }
+                }
+            }
             __syncthreads();
             const int n_epi = (MODE == MODE_VEC) ? 8 : 128;
             if (tid < n_epi) {
                 const int m = tid >> 3, p = tid & 7;
                 if (m < M) {
+                    if (PRO == PRO_RMSNORM && it == 0) {
+                        float tot = 0.f;
+                        for (int w = 0; w < nwaves; ++w) tot += red2[m * nwaves + w];
+                        rstd = rsqrtf(tot / (float)a.K + a.eps);
+                    }
                     float v0 = 0.f, v1 = 0.f;
                     for (int w = 0; w < nwaves; ++w) {
                         const float* sp = slot + w * PART + m * 16 + 2 * p;
                         v0 += sp[0]; v1 += sp[1];
                     }
+                    if (PRO == PRO_RMSNORM) { v0 *= rstd; v1 *= rstd; }
                     epilogue_pair<DT, EPI>(a, rg * 16 + 2 * p, m, my_pos, v0, v1, run, side, it, M);
                 }
             }
@@ -440,8 +451,8 @@ __global__ void __launch_bounds__(512) kg_linear_kernel(const KgLinArgs a) {
     // buffer's refill is always "newer" and the counted waits keep it in flight.  A trailing
     // step past the last row group only sees out-of-range (zero) tiles and skips the epilogue.
     do {
-        step(bufA, bufAx);
-        step(bufB, bufBx);
+        step(bufA, bufAx, 0);
+        step(bufB, bufBx, 1);
     } while (rg < G);
     if (EPI == EPI_HEAD) {
         // merge the 8 pair-threads of each column, then one record per (block, column)
@@ -512,13 +523,18 @@ int kg_launch_linear(const KgLinArgs& a_in, int dtype, int max_rows, int pro, in
     size_t side = 0;
     if (epi == EPI_RESID) side = (size_t)((G + nblocks - 1) / nblocks) * max_rows * 16 * 2;
     if (epi == EPI_ROPE_KV) side = (size_t)max_rows * a.head_dim * 4;
-    side = (side + 255) / 256 * 256;
+    side = (side + 255) / 256 * 256 + 512;          // + [rows][nwaves] floats for the deferred RMSNorm reduction
     a.side_bytes = (int)side;
     size_t smem = side + kg_linear_smem(mode != MODE_VEC, max_rows, a.K, nwaves);
     if (mode == MODE_MFMA) {
         // X rows that would leave less than two blocks per CU (or not fit at all) are read
         // as B fragments straight from global memory (L2) when no prologue has to rewrite them
-        if (pro == PRO_NONE && smem > 80 * 1024) { mode = MODE_MFMA_GX; smem = side + (size_t)2 * nwaves * 256 * 4; }
+        if (pro == PRO_NONE && smem > 80 * 1024) {
+            mode = MODE_MFMA_GX;
+            a.gx_slot_rows = max_rows <= 8 ? 8 : 16;
+            smem = side + (size_t)2 * nwaves * 256 * 4 + (size_t)nwaves * 2 * a.gx_slot_rows * (8 * 64 + 16);
+            if (smem > KG_LDS_LIMIT) return -3;
+        }
         else if (smem > KG_LDS_LIMIT) return -3;
     }
     dim3 grid(nblocks), block(nwaves * 64);

@@ -170,6 +170,9 @@ class KangarooEngine:
         for k, v in kw.items():
             _lib.check(self.lib.kg_session_set(self._handle, k.encode(), int(v)), f"kg_session_set({k})")
 
+    def get_tuning(self, key: str) -> int:
+        return int(self.lib.kg_session_get(self._handle, key.encode()))
+
     def weight_bytes(self) -> Dict[str, int]:
         s = self.shape
         return {"layer": s.layer_weight_bytes(), "adapter": s.attn_only_weight_bytes(), "head": s.head_weight_bytes(),

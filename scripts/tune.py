@@ -12,8 +12,9 @@ base, adapter = synth_state_dicts(shape, 2, seed=0, dtype=torch.float16, recipe=
 model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, 2, release_source=True)
 eng = model.engine
 for rows in (1, 7):
-    key_b, key_w = ("vec_blocks_per_cu", "vec_waves") if rows == 1 else ("mfma_blocks_per_cu", "mfma_waves")
+    mode = "vec" if rows == 1 else "mfma"
     for op in ("qkv", "o", "gateup", "down", "head"):
+        key_b, key_w = f"{mode}.{op}.blocks_per_cu", f"{mode}.{op}.waves"
         res = []
         for bpc, w in itertools.product((1, 2, 3, 4, 6, 8), (2, 4, 8)):
             eng.set_tuning(**{key_b: bpc, key_w: w})
