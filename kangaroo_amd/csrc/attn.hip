@@ -5,7 +5,11 @@
 // (1 KiB, fully coalesced), LPR = hd/8 lanes per row.  Scores use v_dot2 + an
 // LPR-lane shuffle reduction, softmax is online (running max / sum per row) in fp32,
 // P.V accumulates per lane for its 8 head dims.  Waves of a block, then T-splits, are
-// merged with the usual (max, sum, acc) rule; the causal bound of row m is its own
+// merged with the usual (max, sum, acc) rule.  The T-splits of one head meet without a
+// second kernel: every block publishes its partial result with device-coherent stores,
+// then bumps a per-head counter; the block that arrives last reads all partials back and
+// writes the final rows (always summing in split order, so the result does not depend on
+// which block that is).  The causal bound of row m is its own
 // cache slot pos[m] (keys at slots > pos[m] are excluded), which replaces the
 // reference's additive mask tensors (kangaroo/adapter.py:38-67, 327-348).
 #include "kg_common.h"
@@ -13,6 +17,49 @@
 
 #define ATT_U 4         // K and V loads in flight per lane per batch
 #define ATT_NW 4        // waves per block
+
+#define KG_AGENT __HIP_MEMORY_SCOPE_AGENT
+
+// Device-coherent access to the split partials: these bypass the per-XCD L2, so a block on
+// another XCD reads what was written without any cache maintenance in between.
+__device__ __forceinline__ void coh_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, KG_AGENT); }
+__device__ __forceinline__ float coh_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, KG_AGENT); }
+
+// Called by every thread of a block after its partial stores.  Returns true in all threads
+// of the block that completed the head's set of n_act partials (and re-arms the counter).
+__device__ __forceinline__ bool split_arrive(unsigned* counter, int n_act) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's partial stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, KG_AGENT);
+        const int last = (old == (unsigned)(n_act - 1));
+        if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, KG_AGENT);
+        s_last = last;
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
+// out[m][h][:] = sum_s w_s o_s / sum_s w_s l_s,  w_s = exp(m_s - max_s m_s), rows m0 .. m0+mr-1
+template <int DT>
+__device__ __forceinline__ void split_combine(const KgAttnArgs& a, int h, int hd, int m0, int mr, int ns) {
+    typedef KgT<DT> T;
+    for (int i = threadIdx.x; i < mr * hd; i += blockDim.x) {
+        const int m = m0 + i / hd, dmi = i % hd;
+        float mx = -INFINITY;
+        for (int s = 0; s < ns; ++s) mx = fmaxf(mx, coh_load(a.part_ml + (((size_t)s * a.max_rows + m) * a.H + h) * 2));
+        float o = 0.f, l = 0.f;
+        for (int s = 0; s < ns; ++s) {
+            const float* ml = a.part_ml + (((size_t)s * a.max_rows + m) * a.H + h) * 2;
+            const float m_s = coh_load(ml);
+            const float f = (m_s == -INFINITY) ? 0.f : expf(m_s - mx);
+            o += f * coh_load(a.part_o + (((size_t)s * a.max_rows + m) * a.H + h) * hd + dmi);
+            l += f * coh_load(ml + 1);
+        }
+        ((unsigned short*)a.out)[(size_t)m * a.H * hd + (size_t)h * hd + dmi] = T::from_f(o / l);
+    }
+}
 
 template <int DT, int LPR, int MR>
 __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_kernel(const KgAttnArgs a) {
@@ -23,7 +70,7 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_kernel(const KgAttnArgs a
     const int m0 = blockIdx.z * MR;
     if (m0 >= M) return;
     const int mr = min(MR, M - m0);
-    const int len = dyn->pos[M - 1] + 1;
+    const int len = dyn->pos[0] + M;               // rows of a pass sit at consecutive positions
     const int h = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
     const int hd = LPR * 8;
     const int kvh = h / (a.H / a.Hkv);
@@ -158,13 +205,14 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_kernel(const KgAttnArgs a
         if (n_act == 1) {
             ((unsigned short*)a.out)[(size_t)mm * a.H * hd + (size_t)h * hd + dmi] = T::from_f(o / l);
         } else {
-            a.part_o[(((size_t)split * a.max_rows + mm) * a.H + h) * hd + dmi] = o;
+            coh_store(a.part_o + (((size_t)split * a.max_rows + mm) * a.H + h) * hd + dmi, o);
             if (dmi == 0) {
                 float* ml = a.part_ml + (((size_t)split * a.max_rows + mm) * a.H + h) * 2;
-                ml[0] = mx; ml[1] = l;
+                coh_store(ml, mx); coh_store(ml + 1, l);
             }
         }
     }
+    if (n_act > 1 && split_arrive(a.counters + blockIdx.z * a.H + h, n_act)) split_combine<DT>(a, h, hd, m0, mr, n_act);
 }
 
 // ---------------------------------------------------------------------------------
@@ -187,7 +235,7 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnA
     const int pos_c = dyn->pos[c];
     if (dyn->active == 0) return;
     const int M = dyn->n_rows;
-    const int len = dyn->pos[M - 1] + 1;
+    const int len = __shfl(pos_c, 0, 64) + M;      // rows of a pass sit at consecutive positions
     const int h = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
     const int kvh = h / (a.H / a.Hkv);
     constexpr int KS = HD / 32;                    // k-steps of the score MFMAs
@@ -297,42 +345,14 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnA
         if (n_act == 1) {
             ((unsigned short*)a.out)[((size_t)m * a.H + h) * HD + dmi] = T::from_f(o / l);
         } else {
-            a.part_o[(((size_t)split * a.max_rows + m) * a.H + h) * HD + dmi] = o;
+            coh_store(a.part_o + (((size_t)split * a.max_rows + m) * a.H + h) * HD + dmi, o);
             if (dmi == 0) {
                 float* ml = a.part_ml + (((size_t)split * a.max_rows + m) * a.H + h) * 2;
-                ml[0] = mx; ml[1] = l;
+                coh_store(ml, mx); coh_store(ml + 1, l);
             }
         }
     }
-}
-
-// out[m][h][:] = sum_s w_s o_s / sum_s w_s l_s,  w_s = exp(m_s - max_s m_s)
-template <int DT>
-__global__ void kg_attn_combine_kernel(const KgAttnArgs a) {
-    typedef KgT<DT> T;
-    const KgDyn* dyn = a.dyn;
-    if (dyn->active == 0) return;
-    const int M = dyn->n_rows;
-    const int h = blockIdx.x, m = blockIdx.y;
-    if (m >= M) return;
-    const int hd = a.hd;
-    const int len = dyn->pos[M - 1] + 1;
-    int chunk = (a.t_max + a.nsplit - 1) / a.nsplit;
-    chunk = (chunk + a.chunk_round - 1) / a.chunk_round * a.chunk_round;
-    const int ns = (len + chunk - 1) / chunk;          // active splits, as the attention kernel counts them
-    if (ns == 1) return;                               // the single split wrote the final rows itself
-    float mx = -INFINITY;
-    for (int s = 0; s < ns; ++s) mx = fmaxf(mx, a.part_ml[(((size_t)s * a.max_rows + m) * a.H + h) * 2]);
-    for (int dmi = threadIdx.x; dmi < hd; dmi += blockDim.x) {
-        float o = 0.f, l = 0.f;
-        for (int s = 0; s < ns; ++s) {
-            const float* ml = a.part_ml + (((size_t)s * a.max_rows + m) * a.H + h) * 2;
-            const float f = (ml[0] == -INFINITY) ? 0.f : expf(ml[0] - mx);
-            o += f * a.part_o[(((size_t)s * a.max_rows + m) * a.H + h) * hd + dmi];
-            l += f * ml[1];
-        }
-        ((unsigned short*)a.out)[(size_t)m * a.H * hd + (size_t)h * hd + dmi] = T::from_f(o / l);
-    }
+    if (n_act > 1 && split_arrive(a.counters + h, n_act)) split_combine<DT>(a, h, HD, 0, M, n_act);
 }
 
 template <int DT, int LPR>
@@ -364,17 +384,11 @@ static int launch_dt(const KgAttnArgs& a, hipStream_t st) {
         default: return -1;
         }
     }
-    if (a.nsplit > 1) {
-        KgAttnArgs c = a;
-        c.chunk_round = a.v_transposed ? 32 : ATT_U * (64 / (a.hd / 8));     // rows per batch of the kernel that ran
-        dim3 grid(a.H, a.max_rows);
-        hipLaunchKernelGGL((kg_attn_combine_kernel<DT>), grid, dim3(a.hd < 64 ? 64 : a.hd), 0, st, c);
-    }
     return 0;
 }
 
 int kg_launch_attn(const KgAttnArgs& a, int dtype, hipStream_t st) {
-    if (a.nsplit < 1 || a.max_rows < 1 || a.max_rows > KG_MAX_ROWS || a.H % a.Hkv != 0) return -1;
+    if (!a.counters || a.nsplit < 1 || a.max_rows < 1 || a.max_rows > KG_MAX_ROWS || a.H % a.Hkv != 0) return -1;
     if (a.v_transposed && (a.t_max % 32 != 0)) return -1;
     int rc = (dtype == KG_F16) ? launch_dt<KG_F16>(a, st) : launch_dt<KG_BF16>(a, st);
     if (rc) return rc;

@@ -41,6 +41,7 @@ struct kg_session {
     KgDyn *dyn_shallow, *dyn_adapter, *dyn_verify, *dyn_call;
     char *h, *h2, *xq, *attn_out, *act, *exited, *prev_exit, *adapter_in, *adapter_h, *hs_early;
     float *part_o, *part_ml, *head_part;
+    unsigned* attn_counters;
     int* head_tok; float* head_pmax;
     int head_part_stride;
     int prefill_rows;
@@ -90,6 +91,7 @@ static void carve(kg_session* s, Carver& c, const kg_shape* sh, int t_max) {
     const int nsplit_max = 32;
     float* part_o = c.take<float>((size_t)nsplit_max * R * qd);
     float* part_ml = c.take<float>((size_t)nsplit_max * R * sh->num_heads * 2);
+    unsigned* attn_counters = c.take<unsigned>(2 * (size_t)sh->num_heads);
     const int hp_stride = (sh->vocab_size + 15) / 16;
     float* head_part = c.take<float>((size_t)R * hp_stride * 4);
     int* head_tok = c.take<int>(R);
@@ -99,7 +101,7 @@ static void carve(kg_session* s, Carver& c, const kg_shape* sh, int t_max) {
         s->dyn_shallow = dyn; s->dyn_adapter = dyn + 1; s->dyn_verify = dyn + 2; s->dyn_call = dyn + 3;
         s->h = h; s->h2 = h2; s->xq = xq; s->attn_out = attn_out; s->act = act; s->exited = exited;
         s->prev_exit = prev_exit; s->adapter_in = adapter_in; s->adapter_h = adapter_h; s->hs_early = hs_early;
-        s->part_o = part_o; s->part_ml = part_ml; s->head_part = head_part; s->head_part_stride = hp_stride;
+        s->part_o = part_o; s->part_ml = part_ml; s->attn_counters = attn_counters; s->head_part = head_part; s->head_part_stride = hp_stride;
         s->head_tok = head_tok; s->head_pmax = head_pmax;
     }
 }
@@ -130,6 +132,7 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     Carver c{(char*)buffers->workspace, 0};
     carve(s, c, shape, buffers->t_max);
     s->prefill_rows = prefill_rows_for(shape);
+    if (hipMemset(s->attn_counters, 0, 2 * (size_t)shape->num_heads * sizeof(unsigned)) != hipSuccess) { delete s; return fail(-2, "hipMemset failed"); }
     for (int op = 0; op < 5; ++op) { s->waves[0][op] = 8; s->bpc[0][op] = 2; s->waves[1][op] = 8; s->bpc[1][op] = 1; }
     s->waves[0][1] = 4; s->waves[0][3] = 4;      // o_proj, down_proj: one row group per block, 4 waves measured best
     s->waves[1][3] = 2;                          // down_proj in the large-K MFMA mode
@@ -247,7 +250,7 @@ static int run_layer(kg_session* s, const kg_layer_weights& lw, void* kc, void* 
         memset(&a, 0, sizeof(a));
         a.dyn = dyn; a.q = s->xq; a.k_cache = kc; a.v_cache = vc;
         a.H = sh.num_heads; a.Hkv = sh.num_kv_heads; a.hd = sh.head_dim; a.t_max = s->buf.t_max; a.v_transposed = s->v_transposed;
-        a.nsplit = s->attn_nsplit; a.part_o = s->part_o; a.part_ml = s->part_ml; a.out = s->attn_out; a.max_rows = max_rows;
+        a.nsplit = s->attn_nsplit; a.part_o = s->part_o; a.part_ml = s->part_ml; a.counters = s->attn_counters; a.out = s->attn_out; a.max_rows = max_rows;
         KG_TRY(kg_launch_attn(a, dt, st));
     }
     const bool attn_only = (lw.wgu == nullptr);
@@ -686,7 +689,7 @@ extern "C" int kg_qkv_rope_append(int dtype, const void* wqkv_packed, int d, int
 }
 
 extern "C" size_t kg_attention_scratch_bytes(int n_heads, int head_dim, int nsplit) {
-    return 256 + (size_t)nsplit * KG_MAX_ROWS * n_heads * (head_dim + 2) * sizeof(float) + 512;
+    return 256 + (size_t)nsplit * KG_MAX_ROWS * n_heads * (head_dim + 2) * sizeof(float) + 256 + 2 * (size_t)n_heads * sizeof(unsigned);
 }
 
 extern "C" int kg_attention(int dtype, const void* q, int n_rows, int pos0, const void* k_cache, const void* v_cache,
@@ -705,6 +708,8 @@ extern "C" int kg_attention(int dtype, const void* q, int n_rows, int pos0, cons
     a.nsplit = nsplit; a.max_rows = n_rows;
     a.part_o = (float*)((char*)scratch + 256);
     a.part_ml = a.part_o + (size_t)nsplit * KG_MAX_ROWS * n_heads * head_dim;
+    a.counters = (unsigned*)(((uintptr_t)(a.part_ml + (size_t)nsplit * KG_MAX_ROWS * n_heads * 2) + 255) & ~(uintptr_t)255);
+    KG_CHECK_HIP(hipMemsetAsync(a.counters, 0, 2 * (size_t)n_heads * sizeof(unsigned), st));
     // partial buffers are indexed with max_rows = n_rows, within the KG_MAX_ROWS-sized scratch
     a.out = out;
     int rc = kg_launch_attn(a, dtype, st);

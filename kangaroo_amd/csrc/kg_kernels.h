@@ -42,9 +42,9 @@ struct KgAttnArgs {
     int nsplit;
     float* part_o;              // [nsplit][rows][H][hd]
     float* part_ml;             // [nsplit][rows][H][2]
+    unsigned* counters;         // [2][H] arrival counters of the split merge; zero between launches
     void* out;                  // [n_rows, H*hd]
     int max_rows;
-    int chunk_round;            // set by the launcher for the combine kernel
 };
 int kg_launch_attn(const KgAttnArgs& a, int dtype, hipStream_t st);
 

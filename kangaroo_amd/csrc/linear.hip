@@ -216,12 +216,46 @@ __global__ void __launch_bounds__(512) kg_linear_kernel(const KgLinArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
     // one round trip for all per-pass parameters: switch, row count, positions (lane l holds pos[l])
     const int posv = (EPI == EPI_ROPE_KV) ? dyn->pos[lane & (KG_MAX_ROWS - 1)] : 0;
-    if (dyn->active == 0) return;
+    const int active = dyn->active;
     const int n_rows = dyn->n_rows;
+    constexpr int KG_U = (MODE == MODE_MFMA) ? KG_U_MFMA : KG_U_VEC;
+    // Multi-row passes (verify, prefill) are never switched off mid-round, so their first batch
+    // of weight tiles is requested before the parameters above have arrived: the weight
+    // stream starts one memory round trip earlier.  Single-row (draft) passes are often
+    // switched off and would waste that traffic; they look at the switch first.
+    constexpr bool EARLY = false;
+    const int G = (a.N + 15) >> 4, KT = a.K >> 5;
+    const int t0 = (KT * wave) / nwaves, t1 = (KT * (wave + 1)) / nwaves;
+    // Weight tiles come through buffer loads: every load instruction is unconditional (so the
+    // compiler's counted waits stay exact and nothing branches around a load), and a tile
+    // past the wave's k-range or past the block's last row group gets an out-of-range
+    // offset, which the hardware range check answers with zeros without touching memory.
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (int)((size_t)G * KT * 1024), 0x00020000);
+    auto issue_w = [&](kg_u4 (&wv)[KG_U], int lrg, int lt) {
+        const unsigned base = (unsigned)lrg * (unsigned)KT * 1024u + (unsigned)lane * 16u;
+#pragma unroll
+        for (int u = 0; u < KG_U; ++u) {
+            const bool ok = (lrg < G) && (lt + u < t1);
+            const unsigned off = ok ? base + (unsigned)(lt + u) * 1024u : 0xFFFFFFFFu;
+            wv[u] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 2);
+        }
+    };
+    kg_u4 bufA[KG_U], bufB[KG_U];
+    kg_u4 bufAx[KG_U], bufBx[KG_U];
+    if (EARLY) issue_w(bufA, blockIdx.x, t0);
+    if (active == 0) {
+        // the early tiles are "used" on this path too, which keeps their loads above the branch
+        if (EARLY) {
+            unsigned t = 0;
+#pragma unroll
+            for (int u = 0; u < KG_U; ++u) t |= bufA[u].x;
+            asm volatile("" ::"v"(t));
+        }
+        return;
+    }
     const int M = (MODE == MODE_VEC) ? 1 : n_rows;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RM = (MODE == MODE_VEC) ? 1 : KG_MAX_ROWS;
-    constexpr int KG_U = (MODE == MODE_MFMA) ? KG_U_MFMA : KG_U_VEC;
     constexpr int GX_ROW = 8 * 64 + 16;                           // bytes of one X row of a batch in a wave's LDS slot (+ pad)
     static_assert(MODE != MODE_MFMA_GX || KG_U == 8, "the X slot layout assumes 8 tiles per batch");
     const int PART = (MODE == MODE_VEC) ? 16 : 256;            // floats per wave partial
@@ -233,8 +267,6 @@ __global__ void __launch_bounds__(512) kg_linear_kernel(const KgLinArgs a) {
     const int xs_stride = a.K * 2 + 32;
     const int nthreads = blockDim.x;
 
-    const int G = (a.N + 15) >> 4, KT = a.K >> 5;
-    const int t0 = (KT * wave) / nwaves, t1 = (KT * (wave + 1)) / nwaves;
     const int tlast = max(t1 - 1, 0);
     const int g = lane >> 4, r = lane & 15;
 
@@ -307,21 +339,13 @@ __global__ void __launch_bounds__(512) kg_linear_kernel(const KgLinArgs a) {
     }
 
     int rg = blockIdx.x;
-    kg_u4 bufA[KG_U], bufB[KG_U];
-    kg_u4 bufAx[KG_U], bufBx[KG_U];
-
-    // Weight tiles come through buffer loads: every load instruction is unconditional (so the
-    // compiler's counted waits stay exact and nothing branches around a load), and a tile
-    // past the wave's k-range or past the block's last row group gets an out-of-range
-    // offset, which the hardware range check answers with zeros without touching memory.
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (int)((size_t)G * KT * 1024), 0x00020000);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0,
         (MODE == MODE_MFMA_GX) ? (int)(((size_t)(M - 1) * a.x_stride + a.K) * 2) : 0, 0x00020000);
     // MODE_MFMA_GX (X too large for LDS as a whole): each wave moves the X columns of its next
     // batch (rows x 8 tiles x 64 B, row-contiguous 512-byte pieces) through a wave-private LDS
     // slot.  The X loads are issued ahead of the batch's weight tiles, so waiting for them
     // never waits for those weights (the counter retires in order).
-    auto issue = [&](kg_u4 (&wv)[KG_U], kg_u4 (&xv)[KG_U], int lrg, int lt) {
+    auto issue_x = [&](kg_u4 (&xv)[KG_U], int lrg, int lt) {
         if (MODE == MODE_MFMA_GX) {
 #pragma unroll
             for (int j = 0; j < KG_U; ++j) {
@@ -331,18 +355,16 @@ __global__ void __launch_bounds__(512) kg_linear_kernel(const KgLinArgs a) {
                 xv[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo, 0, 0);
             }
         }
-        const unsigned base = (unsigned)lrg * (unsigned)KT * 1024u + (unsigned)lane * 16u;
-#pragma unroll
-        for (int u = 0; u < KG_U; ++u) {
-            const bool ok = (lrg < G) && (lt + u < t1);
-            const unsigned off = ok ? base + (unsigned)(lt + u) * 1024u : 0xFFFFFFFFu;
-            wv[u] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 2);
-        }
+    };
+    auto issue = [&](kg_u4 (&wv)[KG_U], kg_u4 (&xv)[KG_U], int lrg, int lt) {
+        issue_x(xv, lrg, lt);
+        issue_w(wv, lrg, lt);
     };
 
     // two batches of weight tiles in flight while the prologue finishes
     int lrg = rg, lt = t0;
-    issue(bufA, bufAx, lrg, lt);
+    if (EARLY) issue_x(bufAx, lrg, lt);
+    else issue(bufA, bufAx, lrg, lt);
     lt += KG_U;
     if (lt >= t1) { lt = t0; lrg += gridDim.x; }
     issue(bufB, bufBx, lrg, lt);

@@ -23,10 +23,15 @@ def main():
     ap.add_argument("--new", type=int, default=256)
     ap.add_argument("--prompts", type=int, default=3)
     ap.add_argument("--tune", default="")
+    ap.add_argument("--plen", type=int, default=0, help="use one random prompt of this many tokens instead of the Spec-Bench-shaped set")
+    ap.add_argument("--modes", default="vanilla,kangaroo")
     a = ap.parse_args()
     shape = get_shape(a.model)
     L = DEFAULT_EXIT_LAYER.get(a.model, 2)
     prompts = spec_bench_prompts(shape.vocab_size, a.prompts)
+    if a.plen:
+        g = torch.Generator().manual_seed(1)
+        prompts = [type("P", (), {"input_ids": torch.randint(3, shape.vocab_size, (1, a.plen), generator=g)})()]
     for rc in a.recipes.split(","):
         ds, hs = [float(x) for x in rc.split(":")]
         t0 = time.time()
@@ -41,7 +46,8 @@ def main():
         wb = shape.layer_weight_bytes() * shape.num_hidden_layers + shape.head_weight_bytes()
         for p in prompts:
             ids = p.input_ids[0]
-            for mode in ("vanilla", "kangaroo"):
+            van = None
+            for mode in a.modes.split(","):
                 eng.generate(ids, 16, mode=mode)     # warm-up + graph capture
                 torch.cuda.synchronize()
                 t0 = time.time()
@@ -55,7 +61,7 @@ def main():
                 else:
                     acc = st.accept_lengths
                     d = st.draft_lengths
-                    line += f" rounds={st.rounds} mean_accept={sum(acc) / max(1, len(acc)):.2f} mean_draft={sum(d) / max(1, len(d)):.2f} lossless={out == van[:len(out)]}"
+                    line += f" rounds={st.rounds} mean_accept={sum(acc) / max(1, len(acc)):.2f} mean_draft={sum(d) / max(1, len(d)):.2f} lossless={van is not None and out == van[:len(out)]}"
                 print(line, flush=True)
         del model, eng
         torch.cuda.empty_cache()

@@ -24,6 +24,61 @@ __global__ void k_stream_read(const kg_u4* p, size_t n16, unsigned* out) {
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// Grid-wide barrier for a persistent kernel whose blocks are all resident: monotone counter,
+// bounded spin (a wave that gives up raises *abort so that every later wait falls through).
+__device__ __forceinline__ void grid_arrive(unsigned* ctr) {
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void grid_wait(unsigned* ctr, unsigned target, unsigned* abort_flag) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > (1u << 22) || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+#define AG __HIP_MEMORY_SCOPE_AGENT
+// variant 0: one counter, acquire/release atomics.  1: one counter, relaxed atomics + explicit fences.
+// 2: one flag word per block (packed), thread t polls block t's flag.  3: per-XCD counters (blockIdx % 8)
+// summed by the pollers.
+template <int VV> __device__ __forceinline__ void gbar(unsigned* base, unsigned phase, unsigned* abort_flag) {
+    const unsigned nb = gridDim.x;
+    constexpr int V = VV & 3;
+    constexpr bool FENCE = VV < 4;
+    __syncthreads();
+    if (VV == 0) { grid_wait((grid_arrive(base), base), phase * nb, abort_flag); return; }
+    if (threadIdx.x == 0) {
+        if (FENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (V == 0) __hip_atomic_fetch_add(base, 1u, __ATOMIC_RELAXED, AG);
+        if (V == 1) __hip_atomic_fetch_add(base, 1u, __ATOMIC_RELAXED, AG);
+        if (V == 2) __hip_atomic_store(base + blockIdx.x, phase, __ATOMIC_RELAXED, AG);
+        if (V == 3) __hip_atomic_fetch_add(base + (blockIdx.x & 7) * 32, 1u, __ATOMIC_RELAXED, AG);
+    }
+    unsigned spins = 0;
+    bool ok = false;
+    if (V <= 1) { if (threadIdx.x == 0) while (!ok) { ok = __hip_atomic_load(base, __ATOMIC_RELAXED, AG) >= phase * nb; if (++spins > (1u << 22)) { *abort_flag = 1; break; } } }
+    if (V == 2) { if (threadIdx.x < nb) while (!ok) { ok = __hip_atomic_load(base + threadIdx.x, __ATOMIC_RELAXED, AG) >= phase; if (++spins > (1u << 22)) { *abort_flag = 1; break; } } }
+    if (V == 3) { if (threadIdx.x < 8) while (!ok) { ok = __hip_atomic_load(base + threadIdx.x * 32, __ATOMIC_RELAXED, AG) >= phase * (nb / 8); if (++spins > (1u << 22)) { *abort_flag = 1; break; } } }
+    __syncthreads();
+    if (FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+template <int V> __global__ __launch_bounds__(512) void k_barrier_chain(unsigned* ctr, unsigned* abort_flag, int phases, float* data) {
+    const unsigned nb = gridDim.x;
+    float v = 0.f;
+    for (int p = 0; p < phases; ++p) {
+        // dependent work: block b writes slot (p&1, b+1), block b+1 reads it after the barrier
+        if (threadIdx.x == 0) __hip_atomic_store(data + (p & 1) * nb + (blockIdx.x + 1) % nb, v + 1.f, __ATOMIC_RELAXED, AG);
+        gbar<V>(ctr, (unsigned)(p + 1), abort_flag);
+        v = __hip_atomic_load(data + (p & 1) * nb + blockIdx.x, __ATOMIC_RELAXED, AG);
+    }
+    if (threadIdx.x == 0) data[2 * nb + blockIdx.x] = v;
+}
+
 static float time_graph(hipStream_t st, hipGraphExec_t ge, int reps) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -81,6 +136,33 @@ int main(int argc, char** argv) {
     CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     kg_linear_init();
     if (what == "all" || what == "launch") bench_launch(st);
+
+    if (what == "all" || what == "barrier") {
+        unsigned* ctr; float* data;
+        CK(hipMalloc(&ctr, 8192)); CK(hipMalloc(&data, 8192));
+        for (int variant = 0; variant < 8; ++variant) {
+            for (int phases : {1000}) {
+                const int nthreads = 512;
+                CK(hipMemsetAsync(ctr, 0, 8192, st)); CK(hipMemsetAsync(data, 0, 8192, st));
+                hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                CK(hipEventRecord(e0, st));
+                if (variant == 0) hipLaunchKernelGGL(k_barrier_chain<0>, dim3(256), dim3(nthreads), 0, st, ctr, ctr + 1024, phases, data);
+                if (variant == 1) hipLaunchKernelGGL(k_barrier_chain<1>, dim3(256), dim3(nthreads), 0, st, ctr, ctr + 1024, phases, data);
+                if (variant == 2) hipLaunchKernelGGL(k_barrier_chain<2>, dim3(256), dim3(nthreads), 0, st, ctr, ctr + 1024, phases, data);
+                if (variant == 4) hipLaunchKernelGGL(k_barrier_chain<4>, dim3(256), dim3(nthreads), 0, st, ctr, ctr + 1024, phases, data);
+                if (variant == 5) hipLaunchKernelGGL(k_barrier_chain<5>, dim3(256), dim3(nthreads), 0, st, ctr, ctr + 1024, phases, data);
+                if (variant == 6) hipLaunchKernelGGL(k_barrier_chain<6>, dim3(256), dim3(nthreads), 0, st, ctr, ctr + 1024, phases, data);
+                if (variant == 7) hipLaunchKernelGGL(k_barrier_chain<7>, dim3(256), dim3(nthreads), 0, st, ctr, ctr + 1024, phases, data);
+                if (variant == 3) hipLaunchKernelGGL(k_barrier_chain<3>, dim3(256), dim3(nthreads), 0, st, ctr, ctr + 1024, phases, data);
+                CK(hipEventRecord(e1, st));
+                CK(hipStreamSynchronize(st));
+                float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+                float h[768]; unsigned ab = 0;
+                CK(hipMemcpy(h, data, sizeof(h), hipMemcpyDeviceToHost)); CK(hipMemcpy(&ab, ctr + 1024, 4, hipMemcpyDeviceToHost));
+                printf("grid barrier variant %d, 256 blocks x %3d threads, %4d phases: %.2f us/phase  (abort %u, chain value %.0f expect %d)\n", variant, nthreads, phases, ms * 1e3 / phases, ab, h[512], phases);
+            }
+        }
+    }
 
     // a pool much larger than the 256 MiB Infinity Cache, walked cyclically
     const size_t pool_bytes = (size_t)3 << 30;
