@@ -133,11 +133,14 @@ int kg_session_destroy(kg_session* s);
 /* kg_session_get: "v_transposed" (layout of buffers.v_cache / av_cache the session expects:
  * 1 when head_dim >= 32 and t_max % 32 == 0), "prefill_rows", or a tuning key; -1 if unknown. */
 int kg_session_get(kg_session* s, const char* key);
-/* tuning knobs (launch geometry; results do not depend on them except "attn_nsplit", which fixes
- * the split boundaries of the attention reduction): "attn_nsplit"; "<mode>_waves" and
- * "<mode>_blocks_per_cu" for all linear ops of a mode, or "<mode>.<op>.waves" /
+/* tuning knobs: "attn_nsplit" (fixes the split boundaries of the attention reduction);
+ * "<mode>_waves" and "<mode>_blocks_per_cu" for all linear ops of a mode, or "<mode>.<op>.waves" /
  * "<mode>.<op>.blocks_per_cu" for one, with mode in {vec (1 row), mfma (2..16 rows)} and op in
- * {qkv, o, gateup, down, head}.  kg_session_get reads the per-op keys back. */
+ * {qkv, o, gateup, down, head}; "persist" (2: run the verify pass and the deep layers of plain
+ * decoding as one persistent kernel with grid barriers, 1: one kernel per op, the default) and
+ * "persist.<op>.waves".  Block counts never change results; wave counts set how K is split
+ * inside a block and therefore the fp32 summation order.  Values must be >= 1.
+ * kg_session_get reads the per-op keys and "persist" (0 / 1) back. */
 int kg_session_set(kg_session* s, const char* key, int value);
 
 /* Device address of a named region of the workspace ("tokens": int32[t_max], "state":

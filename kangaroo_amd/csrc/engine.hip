@@ -29,6 +29,9 @@ static void kg_init_once() {
     g_init = true;
 }
 
+static const char* kg_op_names[5] = {"qkv", "o", "gateup", "down", "head"};
+enum { OP_QKV = 0, OP_O = 1, OP_GATEUP = 2, OP_DOWN = 3, OP_HEAD = 4 };
+
 struct kg_session {
     kg_shape sh;
     kg_weights w;
@@ -50,6 +53,14 @@ struct kg_session {
     int waves[2][5], bpc[2][5];
     int attn_nsplit;
     int v_transposed;
+    // persistent pass kernel: phase programs [0] verify pass, [1] deep layers of plain decoding
+    int persist;                       // 1: multi-row passes of the loop run as one persistent kernel
+    int persist_waves[5];              // weight-streaming waves per linear phase (qkv, o, gateup, down, head)
+    KgPhase* prog_dev[3]; int prog_n[3]; size_t prog_smem[3]; int prog_cap;     // [2]: ad-hoc passes of kg_forward_layers
+    unsigned* bar;                     // [0..255] barrier counters, [256] abort flag
+    char* rot; size_t rot_layer;       // per-layer activation buffers of the persistent passes
+    unsigned long long* tlog;          // phase timeline of the last persistent launch (KG_PERSIST_TLOG=1), else null
+    std::vector<int> prog_kinds[3];
     // graphs
     hipStream_t own_stream;
     hipGraphExec_t round_graph; int round_graph_steps;
@@ -96,7 +107,16 @@ static void carve(kg_session* s, Carver& c, const kg_shape* sh, int t_max) {
     float* head_part = c.take<float>((size_t)R * hp_stride * 4);
     int* head_tok = c.take<int>(R);
     float* head_pmax = c.take<float>(R);
+    const int prog_cap = 5 * sh->num_layers + 2;
+    KgPhase* prog0 = c.take<KgPhase>(prog_cap);
+    KgPhase* prog1 = c.take<KgPhase>(prog_cap);
+    KgPhase* prog2 = c.take<KgPhase>(prog_cap);
+    unsigned* bar = c.take<unsigned>(512);
+    // per-layer activation buffers of the persistent passes: h after attention, h after the MLP, q, attention output, MLP activations
+    const size_t rot_layer = R * (2 * d + 2 * qd + F) * e;
+    char* rot = c.take<char>(rot_layer * sh->num_layers);
     if (s) {
+        s->prog_dev[0] = prog0; s->prog_dev[1] = prog1; s->prog_dev[2] = prog2; s->prog_cap = prog_cap; s->bar = bar; s->rot = rot; s->rot_layer = rot_layer;
         s->state = state; s->tokens = tokens;
         s->dyn_shallow = dyn; s->dyn_adapter = dyn + 1; s->dyn_verify = dyn + 2; s->dyn_call = dyn + 3;
         s->h = h; s->h2 = h2; s->xq = xq; s->attn_out = attn_out; s->act = act; s->exited = exited;
@@ -122,6 +142,7 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     if (buffers->t_max > shape->max_positions) return fail(-1, "t_max exceeds the RoPE table");
     if (buffers->workspace_bytes < kg_workspace_bytes(shape, buffers->t_max)) return fail(-1, "workspace too small");
     kg_init_once();
+    kg_persist_init();
     kg_session* s = new kg_session();
     s->sh = *shape; s->w = *weights; s->buf = *buffers;
     s->layers.assign(weights->layers, weights->layers + shape->num_layers);
@@ -139,6 +160,16 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     s->v_transposed = (shape->head_dim >= 32 && buffers->t_max % 32 == 0) ? 1 : 0;
     s->attn_nsplit = 16;
     s->round_graph = nullptr; s->round_graph_steps = -1; s->vanilla_graph = nullptr;
+    s->prog_n[0] = s->prog_n[1] = s->prog_n[2] = 0;
+    for (int op = 0; op < 5; ++op) s->persist_waves[op] = 8;
+    s->persist_waves[OP_DOWN] = 4;
+    // Off by default: measured on MI355X at the 7B shape the software grid barrier (3-4.5 us per
+    // phase as block 0 sees it, against ~1.6 us for a kernel boundary inside a graph) costs what
+    // the uninterrupted weight stream wins; set "persist" = 2 to run the passes this way.
+    s->persist = 0;
+    s->tlog = nullptr;
+    if (getenv("KG_PERSIST_TLOG") && hipMalloc((void**)&s->tlog, (2 * (size_t)s->prog_cap + 2) * sizeof(unsigned long long)) != hipSuccess) s->tlog = nullptr;
+    if (hipMemset(s->bar, 0, 512 * sizeof(unsigned)) != hipSuccess) { delete s; return fail(-2, "hipMemset failed"); }
     if (hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking) != hipSuccess) { delete s; return fail(-2, "hipStreamCreate failed"); }
     if (hipHostMalloc((void**)&s->host_state, 4 * 64 * sizeof(int)) != hipSuccess) { delete s; return fail(-2, "hipHostMalloc failed"); }
     hipEventCreateWithFlags(&s->ev[0], hipEventDisableTiming);
@@ -162,15 +193,15 @@ extern "C" int kg_session_destroy(kg_session* s) {
     return 0;
 }
 
-static const char* kg_op_names[5] = {"qkv", "o", "gateup", "down", "head"};
-enum { OP_QKV = 0, OP_O = 1, OP_GATEUP = 2, OP_DOWN = 3, OP_HEAD = 4 };
-
 extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
     if (!s || !key) return fail(-1, "null argument");
     std::string k(key);
     if (value < 1) return fail(-1, "value must be >= 1");
     bool done = false;
     if (k == "attn_nsplit") { if (value > 32) return fail(-1, "nsplit <= 32"); s->attn_nsplit = value; done = true; }
+    if (k == "persist") { s->persist = (value >= 2 && s->v_transposed && (g_ncu % 8) == 0) ? 1 : 0; done = true; }   // 1: off, 2: on
+    for (int op = 0; op < 5 && !done; ++op)
+        if (k == std::string("persist.") + kg_op_names[op] + ".waves") { if (value > 8) return fail(-1, "waves <= 8"); s->persist_waves[op] = value; done = true; }
     for (int mode = 0; mode < 2 && !done; ++mode) {
         const std::string mname = mode == 0 ? "vec" : "mfma";
         if (k == mname + "_waves") { if (value > 8) return fail(-1, "waves <= 8"); for (int op = 0; op < 5; ++op) s->waves[mode][op] = value; done = true; }
@@ -184,6 +215,7 @@ extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
     // graphs bake the launch geometry in
     if (s->round_graph) { hipGraphExecDestroy(s->round_graph); s->round_graph = nullptr; s->round_graph_steps = -1; }
     if (s->vanilla_graph) { hipGraphExecDestroy(s->vanilla_graph); s->vanilla_graph = nullptr; }
+    s->prog_n[0] = s->prog_n[1] = s->prog_n[2] = 0;
     return 0;
 }
 
@@ -199,6 +231,7 @@ extern "C" int kg_session_get(kg_session* s, const char* key) {
         }
     }
     if (k == "attn_nsplit") return s->attn_nsplit;
+    if (k == "persist") return s->persist;
     if (k == "prefill_rows") return s->prefill_rows;
     return -1;
 }
@@ -302,6 +335,9 @@ static KgLoopBufs loop_bufs(kg_session* s) {
     return b;
 }
 
+static int build_program(kg_session* s, int which, const KgDyn* dyn, int max_rows, int l0, int l1, const void* x_in, void* hbuf, bool with_head);
+static int run_program(kg_session* s, int which, hipStream_t st);
+
 // ---------------------------------------------------------------------------------
 // model-level entry points
 // ---------------------------------------------------------------------------------
@@ -328,6 +364,21 @@ extern "C" int kg_forward_layers(kg_session* s, int layer_begin, int layer_end, 
     if (!x_in) {
         KG_TRY(kg_launch_embed(s->dyn_call, s->tokens, s->w.embed, d, s->h, d, st));
         cur = s->h;
+    }
+    if (s->persist && n_rows >= 2) {
+        // the whole pass as one persistent kernel (rows live in the session's h2 buffer meanwhile)
+        KG_CHECK_HIP(hipStreamSynchronize(st));
+        KG_TRY(build_program(s, 2, s->dyn_call, max_rows, layer_begin, layer_end, cur, s->h2, false));
+        if (s->prog_n[2] > 0) {
+            KG_CHECK_HIP(hipMemsetAsync(s->bar + 256, 0, sizeof(unsigned), st));
+            KG_TRY(run_program(s, 2, st));
+            KG_CHECK_HIP(hipMemcpyAsync(h_out, s->h2, (size_t)n_rows * d * s->elt, hipMemcpyDeviceToDevice, st));
+            unsigned aborted = 0;
+            KG_CHECK_HIP(hipMemcpyAsync(&aborted, s->bar + 256, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            KG_CHECK_HIP(hipStreamSynchronize(st));
+            if (aborted) { s->persist = 0; return fail(-4, "persistent pass timed out at a grid barrier; persistent passes are now off for this session, call again"); }
+            return 0;
+        }
     }
     for (int l = layer_begin; l < layer_end; ++l) {
         void* dst = (l == layer_end - 1) ? h_out : (void*)s->h;
@@ -374,6 +425,100 @@ extern "C" int kg_head_logits(kg_session* s, const void* x, int n_rows, void* lo
 }
 
 // ---------------------------------------------------------------------------------
+// persistent passes
+// ---------------------------------------------------------------------------------
+// Phase list of layers [l0, l1) + lm_head on the rows of dyn (<= max_rows): the same ops with
+// the same arguments as run_layer / run_head issue kernel by kernel.  Returns 0 and leaves
+// prog_n[which] = 0 when the pass cannot run persistently (the caller then launches kernels).
+static int build_program(kg_session* s, int which, const KgDyn* dyn, int max_rows, int l0, int l1, const void* x_in, void* hbuf, bool with_head) {
+    const kg_shape& sh = s->sh;
+    const int d = sh.hidden_size, F = sh.intermediate_size, nblk = g_ncu;
+    s->prog_n[which] = 0;
+    if (!s->persist || max_rows < 2 || 5 * (l1 - l0) + 1 > s->prog_cap) return 0;
+    std::vector<KgPhase> prog;
+    size_t smem = kg_persist_attn_smem(sh.head_dim);
+    if (smem == 0) return 0;
+    auto add_lin = [&](int kind, int op, const KgLinArgs& a) -> bool {
+        KgPhase p;
+        memset(&p, 0, sizeof(p));
+        p.kind = kind; p.nwaves = s->persist_waves[op]; p.lin = a;
+        const size_t need = kg_persist_plan_linear(p, max_rows, nblk);
+        if (need == 0) return false;
+        if (need > smem) smem = need;
+        prog.push_back(p);
+        return true;
+    };
+    // Every layer works in buffers of its own: within one launch a buffer is written once (by
+    // one phase) and read by later phases only, which is what lets those reads be ordinary
+    // cached loads (see KG_PERSIST_COH_LOADS).  The last layer writes the caller's hbuf.
+    const size_t R = KG_MAX_ROWS, e = s->elt;
+    const void* cur = x_in;
+    for (int l = l0; l < l1; ++l) {
+        const kg_layer_weights& lw = s->layers[l];
+        char* base = s->rot + (size_t)l * s->rot_layer;
+        void* hmid = base;
+        void* hout = (l == l1 - 1) ? hbuf : (void*)(base + R * d * e);
+        void* xq = base + 2 * R * d * e;
+        void* ao = base + (2 * R * d + R * (size_t)s->q_dim) * e;
+        void* act = base + (2 * R * d + 2 * R * (size_t)s->q_dim) * e;
+        {
+            KgLinArgs a = lin_base(dyn, lw.wqkv, s->q_dim + 2 * s->kv_dim, d, cur, d);
+            a.norm_w = lw.norm1; a.eps = sh.rms_eps;
+            a.q_out = xq; a.k_cache = layer_k(s, l); a.v_cache = layer_v(s, l);
+            a.rope_cos = s->w.rope_cos; a.rope_sin = s->w.rope_sin;
+            a.head_dim = sh.head_dim; a.q_dim = s->q_dim; a.kv_dim = s->kv_dim; a.t_max = s->buf.t_max; a.v_transposed = 1;
+            if (!add_lin(KG_PH_QKV, OP_QKV, a)) return 0;
+        }
+        {
+            KgPhase p;
+            memset(&p, 0, sizeof(p));
+            p.kind = KG_PH_ATTN; p.nwaves = 8;
+            KgAttnArgs& a = p.attn;
+            a.dyn = dyn; a.q = xq; a.k_cache = layer_k(s, l); a.v_cache = layer_v(s, l);
+            a.H = sh.num_heads; a.Hkv = sh.num_kv_heads; a.hd = sh.head_dim; a.t_max = s->buf.t_max; a.v_transposed = 1;
+            a.nsplit = s->attn_nsplit; a.part_o = s->part_o; a.part_ml = s->part_ml; a.counters = s->attn_counters; a.out = ao; a.max_rows = max_rows;
+            prog.push_back(p);
+        }
+        {
+            KgLinArgs a = lin_base(dyn, lw.wo, d, s->q_dim, ao, s->q_dim);
+            a.out = hmid; a.out_stride = d; a.resid = cur; a.resid_stride = d;
+            if (!add_lin(KG_PH_O, OP_O, a)) return 0;
+        }
+        {
+            KgLinArgs a = lin_base(dyn, lw.wgu, 2 * F, d, hmid, d);
+            a.norm_w = lw.norm2; a.eps = sh.rms_eps;
+            a.out = act; a.out_stride = F;
+            if (!add_lin(KG_PH_GATEUP, OP_GATEUP, a)) return 0;
+        }
+        {
+            KgLinArgs a = lin_base(dyn, lw.wdown, d, F, act, F);
+            a.out = hout; a.out_stride = d; a.resid = hmid; a.resid_stride = d;
+            if (!add_lin(KG_PH_DOWN, OP_DOWN, a)) return 0;
+        }
+        cur = hout;
+    }
+    if (with_head) {
+        KgLinArgs a = lin_base(dyn, s->w.lm_head, sh.vocab_size, d, cur, d);
+        a.norm_w = s->w.final_norm; a.eps = sh.rms_eps;
+        a.head_part = s->head_part; a.head_part_stride = s->head_part_stride;
+        a.logits_stride = sh.vocab_size;
+        if (!add_lin(KG_PH_HEAD, OP_HEAD, a)) return 0;
+    }
+    if (kg_persist_max_blocks(sh.dtype, smem) < nblk) return 0;
+    KG_CHECK_HIP(hipMemcpy(s->prog_dev[which], prog.data(), prog.size() * sizeof(KgPhase), hipMemcpyHostToDevice));
+    s->prog_n[which] = (int)prog.size();
+    s->prog_kinds[which].clear();
+    for (auto& p : prog) s->prog_kinds[which].push_back(p.kind);
+    s->prog_smem[which] = smem;
+    return 0;
+}
+
+static int run_program(kg_session* s, int which, hipStream_t st) {
+    KG_CHECK_HIP(hipMemsetAsync(s->bar, 0, 256 * sizeof(unsigned), st));
+    return kg_launch_persist(s->prog_dev[which], s->prog_n[which], s->bar, s->sh.dtype, g_ncu, s->prog_smem[which], s->tlog, st);
+}
+
+// ---------------------------------------------------------------------------------
 // generate: prefill + graph-replayed rounds
 // ---------------------------------------------------------------------------------
 static int enqueue_round(kg_session* s, int steps, hipStream_t st) {
@@ -404,13 +549,18 @@ static int enqueue_round(kg_session* s, int steps, hipStream_t st) {
     }
     KG_TRY(kg_launch_verify_begin(b, st));
     const int vrows = steps + 1 > 1 ? steps + 1 : 2;
-    const void* cur = s->exited;
-    for (int l = L; l < N; ++l) {
-        KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_verify, vrows, cur, s->h2, st));
-        cur = s->h2;
-    }
     int nb = 0;
-    KG_TRY(run_head(s, s->dyn_verify, vrows, s->h2, 0, s->w.final_norm, nullptr, &nb, st));
+    if (s->prog_n[0] > 0) {
+        KG_TRY(run_program(s, 0, st));
+        nb = grid_for(s, sh.vocab_size, vrows, OP_HEAD);     // both equal the CU count
+    } else {
+        const void* cur = s->exited;
+        for (int l = L; l < N; ++l) {
+            KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_verify, vrows, cur, s->h2, st));
+            cur = s->h2;
+        }
+        KG_TRY(run_head(s, s->dyn_verify, vrows, s->h2, 0, s->w.final_norm, nullptr, &nb, st));
+    }
     KG_TRY(kg_launch_accept(b, s->head_part, s->head_part_stride, nb, st));
     return 0;
 }
@@ -424,10 +574,17 @@ static int enqueue_vanilla(kg_session* s, hipStream_t st) {
     KgLoopBufs b = loop_bufs(s);
     KG_TRY(kg_launch_vanilla_begin(b, st));
     KG_TRY(kg_launch_embed(s->dyn_shallow, s->tokens, s->w.embed, sh.hidden_size, s->h, sh.hidden_size, st));
-    for (int l = 0; l < sh.num_layers; ++l)
-        KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_shallow, l < sh.exit_layer ? 1 : 2, s->h, s->h, st));
     int nb = 0;
-    KG_TRY(run_head(s, s->dyn_shallow, 2, s->h, 0, s->w.final_norm, nullptr, &nb, st));
+    if (s->prog_n[1] > 0) {
+        for (int l = 0; l < sh.exit_layer; ++l)
+            KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_shallow, 1, s->h, s->h, st));
+        KG_TRY(run_program(s, 1, st));
+        nb = grid_for(s, sh.vocab_size, 2, OP_HEAD);
+    } else {
+        for (int l = 0; l < sh.num_layers; ++l)
+            KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_shallow, l < sh.exit_layer ? 1 : 2, s->h, s->h, st));
+        KG_TRY(run_head(s, s->dyn_shallow, 2, s->h, 0, s->w.final_norm, nullptr, &nb, st));
+    }
     KG_TRY(kg_launch_vanilla_end(b, s->head_part, nb, st));
     return 0;
 }
@@ -435,6 +592,9 @@ static int enqueue_vanilla(kg_session* s, hipStream_t st) {
 static int capture(kg_session* s, int mode, int steps, hipGraphExec_t* out) {
     hipStream_t st = s->own_stream;
     hipGraph_t g = nullptr;
+    KG_CHECK_HIP(hipStreamSynchronize(st));
+    if (mode == 0) KG_TRY(build_program(s, 0, s->dyn_verify, steps + 1 > 1 ? steps + 1 : 2, s->sh.exit_layer, s->sh.num_layers, s->exited, s->h2, true));
+    else KG_TRY(build_program(s, 1, s->dyn_shallow, 2, s->sh.exit_layer, s->sh.num_layers, s->h, s->h2, true));
     KG_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
     int rc = (mode == 0) ? enqueue_round(s, steps, st) : enqueue_vanilla(s, st);
     hipError_t e = hipStreamEndCapture(st, &g);
@@ -521,6 +681,7 @@ extern "C" int kg_generate(kg_session* s, int mode, const int32_t* prompt_host, 
     KG_CHECK_HIP(hipMemcpyAsync(s->state, hs, KS_HDR * sizeof(int), hipMemcpyHostToDevice, st));
     KG_CHECK_HIP(hipMemcpyAsync(s->tokens, prompt_host, (size_t)T0 * sizeof(int), hipMemcpyHostToDevice, st));
 
+    KG_CHECK_HIP(hipMemsetAsync(s->bar + 256, 0, sizeof(unsigned), st));
     KG_CHECK_HIP(hipEventRecord(s->ev_t0, st));
     KG_TRY(prefill(s, T0, mode == 0, st));
     // now arm the real eos / reset the round counter
@@ -563,6 +724,33 @@ extern "C" int kg_generate(kg_session* s, int mode, const int32_t* prompt_host, 
     }
     KG_CHECK_HIP(hipEventRecord(s->ev_t2, st));
     KG_CHECK_HIP(hipStreamSynchronize(st));
+    if (s->prog_n[mode] > 0 && s->tlog) {
+        // timeline of the last persistent launch, as seen by block 0 (100 MHz ticks -> us)
+        const int n = s->prog_n[mode];
+        std::vector<unsigned long long> t(2 * n + 1);
+        KG_CHECK_HIP(hipMemcpy(t.data(), s->tlog, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        static const char* names[7] = {"qkv", "attn", "o", "gateup", "down", "down_gx", "head"};
+        double wait_us[7] = {0}, work_us[7] = {0}; int cnt[7] = {0};
+        for (int i = 0; i < n; ++i) {
+            const int k = s->prog_kinds[mode][i];
+            wait_us[k] += (double)(t[2 * i + 1] - t[2 * i]) * 0.01;
+            work_us[k] += (double)(t[2 * i + 2] - t[2 * i + 1]) * 0.01;
+            cnt[k]++;
+        }
+        fprintf(stderr, "[persist timeline, block 0] total %.1f us over %d phases\n", (double)(t[2 * n] - t[0]) * 0.01, n);
+        for (int k = 0; k < 7; ++k) if (cnt[k]) fprintf(stderr, "  %-8s x%3d  wait %6.2f us  work %6.2f us\n", names[k], cnt[k], wait_us[k] / cnt[k], work_us[k] / cnt[k]);
+    }
+    if (s->prog_n[mode] > 0) {
+        unsigned aborted = 0;
+        KG_CHECK_HIP(hipMemcpy(&aborted, s->bar + 256, sizeof(unsigned), hipMemcpyDeviceToHost));
+        if (aborted) {
+            // a grid barrier gave up: the blocks were not all resident.  Fall back to kernel-by-kernel passes.
+            s->persist = 0; s->prog_n[0] = s->prog_n[1] = 0;
+            if (s->round_graph) { hipGraphExecDestroy(s->round_graph); s->round_graph = nullptr; s->round_graph_steps = -1; }
+            if (s->vanilla_graph) { hipGraphExecDestroy(s->vanilla_graph); s->vanilla_graph = nullptr; }
+            return fail(-4, "persistent pass timed out at a grid barrier; persistent passes are now off for this session, call again");
+        }
+    }
     // the replay queued after the finishing one ran with the loop condition false: a no-op
     const int* fin = slot[final_slot];
     const int sidx = fin[KS_START];

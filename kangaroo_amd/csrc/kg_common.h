@@ -97,6 +97,49 @@ __device__ __forceinline__ float kg_wave_max(float v) {
     return v;
 }
 
+// Grid-wide barrier of a persistent kernel whose blocks are ALL resident (grid <= CUs x
+// blocks per CU).  Arrivals are spread over 8 counters (blockIdx % 8, i.e. one per XCD under
+// round-robin dispatch), 128 B apart; counters only grow within a launch and must be zero at
+// its start.  There is no cache maintenance here: data exchanged across the barrier has to be
+// written and read device-coherently (see KG_AUX_COH / st16 in kg_linear_body.h), and arrive()
+// waits until this thread's stores have been acknowledged.  A wait that spins too long raises
+// *abort_flag, after which every wait falls through, so the grid always drains.
+struct KgGridBar {
+    unsigned* ctr;
+    unsigned* abort_flag;
+    unsigned done;              // barriers this block has signalled
+    unsigned per_ctr;           // arrivals per counter and barrier (gridDim.x / 8)
+    unsigned long long* tlog;   // optional timeline of block 0: [2*i] = phase i entered, [2*i+1] = its wait returned
+    __device__ __forceinline__ void init(unsigned* counters, unsigned* abort_ptr, unsigned long long* timeline) {
+        ctr = counters; abort_flag = abort_ptr; done = 0; per_ctr = gridDim.x >> 3; tlog = timeline;
+    }
+    // every thread of the block, after the phase's last store
+    __device__ __forceinline__ void arrive() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr + (blockIdx.x & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ++done;
+    }
+    // every thread of the block: returns once all blocks have signalled `done` barriers
+    __device__ __forceinline__ void wait() {
+        if (done == 0) { if (tlog && blockIdx.x == 0 && threadIdx.x == 0) tlog[1] = wall_clock64(); return; }
+        if (threadIdx.x < 8) {
+            const unsigned target = done * per_ctr;
+            unsigned spins = 0;
+            while (__hip_atomic_load(ctr + threadIdx.x * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if ((++spins & 63u) == 0) {
+                    if (spins > (1u << 18) || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                        __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tlog && blockIdx.x == 0 && threadIdx.x == 0) tlog[2 * done + 1] = wall_clock64();
+    }
+};
+
 // streamed-once weight load: 16 B per lane, non-temporal
 __device__ __forceinline__ kg_u4 kg_ldg_stream(const kg_u4* p) { return __builtin_nontemporal_load(p); }
 

@@ -48,6 +48,21 @@ struct KgAttnArgs {
 };
 int kg_launch_attn(const KgAttnArgs& a, int dtype, hipStream_t st);
 
+// persistent pass kernel: a list of phases walked by resident blocks (see persist.hip)
+enum { KG_PH_QKV = 0, KG_PH_ATTN = 1, KG_PH_O = 2, KG_PH_GATEUP = 3, KG_PH_DOWN = 4, KG_PH_DOWN_GX = 5, KG_PH_HEAD = 6 };
+struct KgPhase {
+    int kind;
+    int nwaves;                 // waves of a block that stream weights in a linear phase (<= 8)
+    KgLinArgs lin;
+    KgAttnArgs attn;
+};
+size_t kg_persist_plan_linear(KgPhase& p, int max_rows, int nblocks);
+size_t kg_persist_attn_smem(int hd);
+void kg_persist_init();
+int kg_persist_max_blocks(int dtype, size_t smem);
+// tlog: optional device buffer of 2 * n_phases + 1 timestamps (100 MHz ticks) written by block 0
+int kg_launch_persist(const KgPhase* phases_dev, int n_phases, unsigned* bar, int dtype, int nblocks, size_t smem, unsigned long long* tlog, hipStream_t st);
+
 // small control / glue kernels
 int kg_launch_set_dyn(KgDyn* dyn, int active, int n_rows, int pos0, hipStream_t st);
 int kg_launch_embed(const KgDyn* dyn, const int* tokens, const void* embed, int d, void* out, int out_stride, hipStream_t st);

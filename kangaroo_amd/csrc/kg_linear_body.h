@@ -1,0 +1,539 @@
+// Weight-streaming linear kernels for bsz=1 decode (gfx950).
+//
+//   y[m][n] = sum_k X[m][k] * W[n][k]        m < n_rows <= 16
+//
+// W is stored tile-major ("packed"): tile (rg, kt) holds rows 16*rg..16*rg+15 and
+// k = 32*kt..32*kt+31 as 1 KiB in the order [g = k/8][r = row][j = k%8], so that lane
+// l = 16*g + r of a wave reads its 16 B at byte 16*l: every wave-level load is one
+// contiguous 1 KiB, and consecutive k-tiles of a row group are consecutive in memory.
+// The same 16 B are the lane's A fragment of v_mfma_f32_16x16x32 (rows on l&15,
+// k-group on l>>4).
+//
+// Two arithmetic modes share that stream:
+//   VEC   one row (q = 1): v_dot2_f32 per lane, 4-lane k reduction by wave shuffles.
+//   MFMA  up to 16 rows (the (k+1)-token verify pass): X^T is the B operand.
+// A block's waves split K of one row group; partial sums meet in LDS, then a few
+// threads run the fused epilogue (residual add, RoPE + KV append, SiLU*mul, or the
+// lm_head argmax / softmax partials).  The prologue fills X in LDS (plain copy or
+// RMSNorm) after the first weight loads are already in flight.
+#pragma once
+#include "kg_common.h"
+#include "kg_kernels.h"
+
+#ifndef KG_U_VEC
+#define KG_U_VEC 8      // weight tiles (KiB) per batch and wave; two batches are in flight
+#endif
+#ifndef KG_U_MFMA
+#define KG_U_MFMA 8
+#endif
+
+enum { MODE_VEC = 0, MODE_MFMA = 1, MODE_MFMA_GX = 2 };
+
+// Accesses to data that another block wrote earlier in the SAME kernel (persistent passes):
+// device-coherent, i.e. they bypass the per-XCD L2 instead of relying on cache maintenance
+// at a kernel boundary.  COH = false gives the ordinary cached accesses.
+#define KG_AGENT __HIP_MEMORY_SCOPE_AGENT
+#ifndef KG_AUX_COH
+#define KG_AUX_COH 16           // buffer-load cache policy: sc1 (agent scope)
+#endif
+// Persistent passes give every layer its own activation buffers, so a line is written (through
+// to memory) once per launch and only read afterwards: ordinary cached loads then cannot see a
+// stale copy, and the rows are fetched from memory once per XCD instead of once per block.
+// 1 = read them device-coherently anyway (needed if buffers were reused within a launch).
+#ifndef KG_PERSIST_COH_LOADS
+#define KG_PERSIST_COH_LOADS 0
+#endif
+template <bool COH> __device__ __forceinline__ void st16(unsigned short* p, unsigned short v) {
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, KG_AGENT);
+    else *p = v;
+}
+
+template <int DT> __device__ __forceinline__ float silu_mul_ref(float g, float u) {
+    // reference op boundaries: gate, up stored; silu stored; product stored
+    float s = kg_round<DT>(g / (1.0f + expf(-g)));
+    return kg_round<DT>(s * u);
+}
+
+struct HeadRun {
+    float mx; float sum; int idx;
+};
+__device__ __forceinline__ void head_push(HeadRun& h, float v, int n) {
+    if (v > h.mx) {
+        h.sum = h.sum * expf(h.mx - v) + 1.0f;
+        h.mx = v;
+        h.idx = n;
+    } else {
+        h.sum += expf(v - h.mx);
+    }
+}
+__device__ __forceinline__ void head_merge(HeadRun& a, float bmx, float bsum, int bidx) {
+    float M = fmaxf(a.mx, bmx);
+    float sa = (a.mx == -INFINITY) ? 0.0f : a.sum * expf(a.mx - M);
+    float sb = (bmx == -INFINITY) ? 0.0f : bsum * expf(bmx - M);
+    bool take_b = (bmx > a.mx) || (bmx == a.mx && bidx < a.idx);
+    a.idx = take_b ? bidx : a.idx;
+    a.mx = M;
+    a.sum = sa + sb;
+}
+
+// Epilogue for one (row pair, column m).  n0 = packed row index of v0; v1 is row n0+1.
+template <int DT, int EPI, bool COH>
+__device__ __forceinline__ void epilogue_pair(const KgLinArgs& a, int n0, int m, int pos, float v0, float v1, HeadRun& run,
+                                              const char* side, int it, int M) {
+    typedef KgT<DT> T;
+    unsigned short* out = (unsigned short*)a.out;
+    if (EPI == EPI_STORE) {
+        if (n0 < a.N) st16<COH>(&out[(size_t)m * a.out_stride + n0], T::from_f(v0));
+        if (n0 + 1 < a.N) st16<COH>(&out[(size_t)m * a.out_stride + n0 + 1], T::from_f(v1));
+    } else if (EPI == EPI_RESID) {
+        // residual rows of this block were staged in LDS by the prologue: [it][m][16]
+        const unsigned short* res = (const unsigned short*)side + ((size_t)it * M + m) * 16 + (n0 & 15);
+        if (n0 < a.N) st16<COH>(&out[(size_t)m * a.out_stride + n0], T::from_f(T::to_f(res[0]) + kg_round<DT>(v0)));
+        if (n0 + 1 < a.N) st16<COH>(&out[(size_t)m * a.out_stride + n0 + 1], T::from_f(T::to_f(res[1]) + kg_round<DT>(v1)));
+    } else if (EPI == EPI_SILU_MUL) {
+        // packed rows (2i, 2i+1) = (gate_i, up_i)
+        int i = n0 >> 1;
+        if (n0 + 1 < a.N) st16<COH>(&out[(size_t)m * a.out_stride + i], T::from_f(silu_mul_ref<DT>(kg_round<DT>(v0), kg_round<DT>(v1))));
+    } else if (EPI == EPI_ROPE_KV) {
+        // packed rows inside a head: (2j, 2j+1) = original (j, j + hd/2)
+        if (n0 + 1 >= a.N) return;
+        const int hd = a.head_dim, half = hd >> 1;
+        const int head = n0 / hd, hl = n0 - head * hd, j = hl >> 1;
+        float x1 = kg_round<DT>(v0), x2 = kg_round<DT>(v1);
+        if (n0 < a.q_dim + a.kv_dim) {
+            // cos / sin rows of the pass's positions were staged in LDS: [m][2][hd/2]
+            const float* cs = (const float*)side + (size_t)m * hd;
+            float c = kg_round<DT>(cs[j]);
+            float s = kg_round<DT>(cs[half + j]);
+            float o1 = kg_round<DT>(x1 * c) + kg_round<DT>(-x2 * s);
+            float o2 = kg_round<DT>(x2 * c) + kg_round<DT>(x1 * s);
+            x1 = o1; x2 = o2;    // stored through from_f below (one more rounding, as the reference's add)
+        }
+        unsigned short* dst;
+        if (n0 < a.q_dim) {
+            dst = (unsigned short*)a.q_out + (size_t)m * a.q_dim + head * hd;
+        } else if (n0 < a.q_dim + a.kv_dim) {
+            int kvh = head - a.q_dim / hd;
+            dst = (unsigned short*)a.k_cache + ((size_t)kvh * a.t_max + pos) * hd;
+        } else {
+            int kvh = head - (a.q_dim + a.kv_dim) / hd;
+            if (a.v_transposed) {
+                unsigned short* vt = (unsigned short*)a.v_cache + (size_t)kvh * hd * a.t_max + pos;
+                st16<COH>(&vt[(size_t)j * a.t_max], T::from_f(x1));
+                st16<COH>(&vt[(size_t)(j + half) * a.t_max], T::from_f(x2));
+                return;
+            }
+            dst = (unsigned short*)a.v_cache + ((size_t)kvh * a.t_max + pos) * hd;
+        }
+        st16<COH>(&dst[j], T::from_f(x1));
+        st16<COH>(&dst[j + half], T::from_f(x2));
+    } else if (EPI == EPI_HEAD) {
+        float l0 = kg_round<DT>(v0), l1 = kg_round<DT>(v1);
+        if (a.logits_out) {
+            unsigned short* lo = (unsigned short*)a.logits_out;
+            if (n0 < a.N) st16<COH>(&lo[(size_t)m * a.logits_stride + n0], T::from_f(v0));
+            if (n0 + 1 < a.N) st16<COH>(&lo[(size_t)m * a.logits_stride + n0 + 1], T::from_f(v1));
+        }
+        if (n0 < a.N) head_push(run, l0, n0);
+        if (n0 + 1 < a.N) head_push(run, l1, n0 + 1);
+    }
+}
+
+// ---- prologue: fill X rows in LDS -------------------------------------------------
+// xs: LDS base of X, row stride xs_stride bytes.  The whole block works on every row:
+// thread t owns the 16-byte chunks t, t + blockDim, ... of each row, so the sum of squares
+// of a row is formed in the same order whatever the number of rows in the pass.
+//
+// Fast path (a row has at most one chunk per thread): prologue_load issues the chunks of
+// all rows as range-checked buffer loads BEFORE the first weight tiles are requested and
+// keeps them in registers; prologue_finish runs after the weight loads are in flight, so
+// the norm and the LDS fill overlap the first HBM round trip (the memory counter retires
+// in order: x requested first is waited for with the weight loads still outstanding).
+// RMSNorm is applied in two halves: the prologue stores gamma[k] * x[m][k] (rounded to the
+// model dtype) and every thread keeps the sum of squares of the chunks it touched; the row
+// factor rsqrt(mean(x^2) + eps) multiplies the finished dot products in the epilogue, after
+// the partial sums of squares have met in LDS at the first row group's barrier.  The norm
+// therefore costs no barrier and no reduction before the weight stream starts.
+template <int RM> struct ProRegs { kg_u4 v[RM]; kg_u4 gw; };
+
+template <int DT, int PRO, int RM, bool COH_LD>
+__device__ __forceinline__ void prologue_slow(const KgLinArgs& a, char* xs, int xs_stride, float (&ss)[RM], int M, int row_off,
+                                              int tid, int nthreads) {
+    typedef KgT<DT> T;
+    const int nchunk = a.K >> 3;
+    const kg_u4* wn = (const kg_u4*)a.norm_w;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0,
+        (int)(((size_t)(M - 1 + row_off) * a.x_stride + a.K) * 2), 0x00020000);
+#pragma unroll
+    for (int m = 0; m < RM; ++m) {
+        if (m < M) {
+            kg_u4* dst = (kg_u4*)(xs + (size_t)m * xs_stride);
+            for (int c = tid; c < nchunk; c += nthreads) {
+                const kg_u4 xv = __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(((size_t)(m + row_off) * a.x_stride) * 2 + (size_t)c * 16), 0, COH_LD ? KG_AUX_COH : 0);
+                if (PRO == PRO_NONE) { dst[c] = xv; continue; }
+                kg_us8 h = __builtin_bit_cast(kg_us8, xv);
+                kg_us8 g = __builtin_bit_cast(kg_us8, wn[c]);
+                kg_us8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = T::to_f(h[j]);
+                    ss[m] += f * f;
+                    o[j] = T::from_f(T::to_f(g[j]) * f);
+                }
+                dst[c] = __builtin_bit_cast(kg_u4, o);
+            }
+        }
+    }
+}
+
+template <int PRO, int RM, bool COH_LD>
+__device__ __forceinline__ void prologue_load(const KgLinArgs& a, ProRegs<RM>& pr, int M, int row_off, int tid) {
+    const int K = a.K, nchunk = K >> 3;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0,
+        (int)(((size_t)(M - 1 + row_off) * a.x_stride + K) * 2), 0x00020000);
+#pragma unroll
+    for (int m = 0; m < RM; ++m) {
+        const bool ok = (m < M) && (tid < nchunk);
+        const unsigned off = ok ? (unsigned)(((size_t)(m + row_off) * a.x_stride) * 2 + tid * 16) : 0xFFFFFFFFu;
+        pr.v[m] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, COH_LD ? KG_AUX_COH : 0);
+    }
+    if (PRO == PRO_RMSNORM) {
+        const __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc((void*)a.norm_w, 0, K * 2, 0x00020000);
+        pr.gw = __builtin_amdgcn_raw_buffer_load_b128(nr, (tid < nchunk) ? (unsigned)tid * 16u : 0xFFFFFFFFu, 0, 0);
+    }
+}
+
+template <int DT, int PRO, int RM>
+__device__ __forceinline__ void prologue_finish(const KgLinArgs& a, const ProRegs<RM>& pr, char* xs, int xs_stride, float (&ss)[RM], int M,
+                                                int tid) {
+    typedef KgT<DT> T;
+    const int nchunk = a.K >> 3;
+    kg_us8 g = __builtin_bit_cast(kg_us8, pr.gw);
+#pragma unroll
+    for (int m = 0; m < RM; ++m) {
+        if (m < M && tid < nchunk) {
+            if (PRO == PRO_NONE) {
+                *(kg_u4*)(xs + (size_t)m * xs_stride + tid * 16) = pr.v[m];
+            } else {
+                kg_us8 h = __builtin_bit_cast(kg_us8, pr.v[m]);
+                kg_us8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = T::to_f(h[j]);
+                    ss[m] += f * f;
+                    o[j] = T::from_f(T::to_f(g[j]) * f);
+                }
+                *(kg_u4*)(xs + (size_t)m * xs_stride + tid * 16) = __builtin_bit_cast(kg_u4, o);
+            }
+        }
+    }
+}
+
+// The whole linear pass of one block.  PERSIST = false: body of a kernel of its own
+// (blockDim = nwaves * 64).  PERSIST = true: one phase of a persistent pass kernel whose
+// blocks stay resident: the first weight batch is requested BEFORE waiting for the previous
+// phase (weights never depend on it), inputs written by other blocks are read and outputs
+// are written device-coherently, waves beyond `nwaves` only keep the block barriers company,
+// and the phase ends by signalling the grid barrier.
+template <int DT, int MODE, int PRO, int EPI, bool PERSIST>
+__device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, KgGridBar* gb, int nwaves) {
+    typedef KgT<DT> T;
+    constexpr bool COH = PERSIST;                       // outputs: written through to memory
+    constexpr bool COH_LD = PERSIST && KG_PERSIST_COH_LOADS; // inputs written by other blocks earlier in this kernel
+    const KgDyn* dyn = a.dyn;
+    // wave index through readfirstlane: everything derived from it (k-range, loop counters,
+    // row-group cursor) is then provably wave-uniform and the loop's control flow is scalar
+    int tid_ = threadIdx.x;
+    // In a persistent kernel every phase re-derives its per-thread constants from an opaque
+    // copy of the thread index; otherwise they are all hoisted to the kernel's entry and
+    // stay live (and spill) across every other phase.
+    if (PERSIST) asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // one round trip for all per-pass parameters: switch, row count, positions (lane l holds pos[l])
+    constexpr int KG_U = (MODE == MODE_MFMA) ? KG_U_MFMA : KG_U_VEC;
+    constexpr bool EARLY = PERSIST;
+    const bool idle = PERSIST && wave >= nwaves;     // block-uniform per wave
+    const int G = (a.N + 15) >> 4, KT = a.K >> 5;
+    const int t0 = (KT * wave) / nwaves, t1 = (KT * (wave + 1)) / nwaves;
+    // Weight tiles come through buffer loads: every load instruction is unconditional (so the
+    // compiler's counted waits stay exact and nothing branches around a load), and a tile
+    // past the wave's k-range or past the block's last row group gets an out-of-range
+    // offset, which the hardware range check answers with zeros without touching memory.
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (int)((size_t)G * KT * 1024), 0x00020000);
+    auto issue_w = [&](kg_u4 (&wv)[KG_U], int lrg, int lt) {
+        const unsigned base = (unsigned)lrg * (unsigned)KT * 1024u + (unsigned)lane * 16u;
+#pragma unroll
+        for (int u = 0; u < KG_U; ++u) {
+            const bool ok = (lrg < G) && (lt + u < t1);
+            const unsigned off = ok ? base + (unsigned)(lt + u) * 1024u : 0xFFFFFFFFu;
+            wv[u] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 2);
+        }
+    };
+    kg_u4 bufA[KG_U], bufB[KG_U];
+    kg_u4 bufAx[KG_U], bufBx[KG_U];
+    if (EARLY && !idle) {
+        // both batches of the first row group(s): enough bytes in flight to cover the barrier
+        issue_w(bufA, blockIdx.x, t0);
+        int elt = t0 + KG_U, elrg = blockIdx.x;
+        if (elt >= t1) { elt = t0; elrg += gridDim.x; }
+        issue_w(bufB, elrg, elt);
+    }
+    if (PERSIST) gb->wait();
+    const int posv = (EPI == EPI_ROPE_KV) ? dyn->pos[lane & (KG_MAX_ROWS - 1)] : 0;
+    const int active = dyn->active;
+    const int n_rows = dyn->n_rows;
+    if (!PERSIST && active == 0) return;
+    const int M = (MODE == MODE_VEC) ? 1 : n_rows;
+    constexpr int RM = (MODE == MODE_VEC) ? 1 : KG_MAX_ROWS;
+    constexpr int GX_ROW = 8 * 64 + 16;                           // bytes of one X row of a batch in a wave's LDS slot (+ pad)
+    static_assert(MODE != MODE_MFMA_GX || KG_U == 8, "the X slot layout assumes 8 tiles per batch");
+    const int PART = (MODE == MODE_VEC) ? 16 : 256;            // floats per wave partial
+    char* side = smem;                                           // epilogue inputs staged once (residual rows / RoPE rows)
+    float* red2 = (float*)(smem + a.side_bytes - 512);           // [rows][nwaves] partial sums of squares (last 512 B of the side region)
+    float* part = (float*)(smem + a.side_bytes);                 // [2][nwaves][PART]
+    char* xs = smem + a.side_bytes + 2 * nwaves * PART * 4;
+    const int my_pos = (EPI == EPI_ROPE_KV) ? __shfl(posv, (tid >> 3) & (KG_MAX_ROWS - 1), 64) : 0;
+    const int xs_stride = a.K * 2 + 32;
+    const int nthreads = nwaves * 64;
+
+    const int tlast = max(t1 - 1, 0);
+    int bid_ = blockIdx.x;
+    if (PERSIST) asm volatile("" : "+s"(bid_));
+    const int bid = bid_;
+    const int nrg_blk = (G - bid + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (idle) {
+        // same barrier sequence as the working waves: one after the prologue, one per row group
+        __syncthreads();
+        for (int i = 0; i < nrg_blk; ++i) __syncthreads();
+        gb->arrive();
+        return;
+    }
+    const int g = lane >> 4, r = lane & 15;
+
+    // B-operand / x source for this lane
+    const int mrow = (r < M) ? r : 0;
+    const char* xl = xs + (size_t)((MODE == MODE_VEC) ? 0 : mrow) * xs_stride + g * 16;
+
+    // ---- small loads first: X rows and what the epilogues need (residual rows, RoPE rows).
+    // A global load inside the streaming loop would have to be waited for with vmcnt(0),
+    // i.e. drain every weight tile in flight, so everything is fetched here and parked in LDS.
+    const int row_off = (MODE == MODE_VEC && a.x_last_row) ? n_rows - 1 : 0;
+    const bool pro_fast = (a.K >> 3) <= nthreads;
+    ProRegs<RM> pr;
+    float ss[RM];                                                // this thread's share of sum(x^2) per row
+#pragma unroll
+    for (int m = 0; m < RM; ++m) ss[m] = 0.f;
+    if (MODE != MODE_MFMA_GX) {
+        if (pro_fast) prologue_load<PRO, RM, COH_LD>(a, pr, M, row_off, tid);
+        else prologue_slow<DT, PRO, RM, COH_LD>(a, xs, xs_stride, ss, M, row_off, tid, nthreads);
+    }
+    unsigned side_raw[2] = {0u, 0u};
+    const int side_n = (EPI == EPI_RESID) ? nrg_blk * M * 16 : (EPI == EPI_ROPE_KV) ? M * a.head_dim : 0;
+    const bool side_fast = side_n <= 2 * nthreads;
+    if (EPI == EPI_RESID) {
+        if (side_fast) {
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)a.resid, 0,
+                (int)(((size_t)(M - 1) * a.resid_stride + a.N) * 2), 0x00020000);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = tid + e * nthreads;
+                const int row = i & 15, m = (i >> 4) % M, itx = (i >> 4) / M;
+                const int n = ((int)blockIdx.x + itx * (int)gridDim.x) * 16 + row;
+                const bool ok = (i < side_n) && (n < a.N);
+                side_raw[e] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, ok ? (unsigned)(((size_t)m * a.resid_stride + n) * 2) : 0xFFFFFFFFu, 0, COH_LD ? KG_AUX_COH : 0);
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)a.resid, 0,
+                (int)(((size_t)(M - 1) * a.resid_stride + a.N) * 2), 0x00020000);
+            unsigned short* sd = (unsigned short*)side;
+            for (int i = tid; i < side_n; i += nthreads) {
+                const int row = i & 15, m = (i >> 4) % M, itx = (i >> 4) / M;
+                const int n = ((int)blockIdx.x + itx * (int)gridDim.x) * 16 + row;
+                sd[i] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, (n < a.N) ? (unsigned)(((size_t)m * a.resid_stride + n) * 2) : 0xFFFFFFFFu, 0, COH_LD ? KG_AUX_COH : 0);
+            }
+        }
+    } else if (EPI == EPI_ROPE_KV) {
+        const int half = a.head_dim >> 1;
+        if (side_fast) {
+            const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)a.rope_cos, 0, 0x7FFFFFF0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)a.rope_sin, 0, 0x7FFFFFF0, 0x00020000);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = tid + e * nthreads;
+                const int m = i / a.head_dim, jj = i - m * a.head_dim;
+                const int p = __shfl(posv, m & (KG_MAX_ROWS - 1), 64);
+                const bool ok = i < side_n;
+                const unsigned off = (unsigned)(((size_t)p * half + (jj < half ? jj : jj - half)) * 4);
+                const unsigned c = __builtin_amdgcn_raw_buffer_load_b32(cr, (ok && jj < half) ? off : 0xFFFFFFFFu, 0, 0);
+                const unsigned sn = __builtin_amdgcn_raw_buffer_load_b32(sr, (ok && jj >= half) ? off : 0xFFFFFFFFu, 0, 0);
+                side_raw[e] = c | sn;
+            }
+        } else {
+            float* sd = (float*)side;
+            for (int i = tid; i < side_n; i += nthreads) {
+                const int m = i / a.head_dim, jj = i - m * a.head_dim;
+                const int p = dyn->pos[m];
+                sd[i] = (jj < half) ? a.rope_cos[(size_t)p * half + jj] : a.rope_sin[(size_t)p * half + jj - half];
+            }
+        }
+    }
+
+    int rg = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0,
+        (MODE == MODE_MFMA_GX) ? (int)(((size_t)(M - 1) * a.x_stride + a.K) * 2) : 0, 0x00020000);
+    // MODE_MFMA_GX (X too large for LDS as a whole): each wave moves the X columns of its next
+    // batch (rows x 8 tiles x 64 B, row-contiguous 512-byte pieces) through a wave-private LDS
+    // slot.  The X loads are issued ahead of the batch's weight tiles, so waiting for them
+    // never waits for those weights (the counter retires in order).
+    auto issue_x = [&](kg_u4 (&xv)[KG_U], int lrg, int lt) {
+        if (MODE == MODE_MFMA_GX) {
+#pragma unroll
+            for (int j = 0; j < KG_U; ++j) {
+                const int flat = j * 64 + lane, row = flat >> 5, ch = flat & 31;
+                const bool okx = (lrg < G) && (row < M) && (lt + (ch >> 2) < t1);
+                const unsigned xo = okx ? (unsigned)(((size_t)row * a.x_stride) * 2) + (unsigned)lt * 64u + (unsigned)ch * 16u : 0xFFFFFFFFu;
+                xv[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo, 0, COH_LD ? KG_AUX_COH : 0);
+            }
+        }
+    };
+    auto issue = [&](kg_u4 (&wv)[KG_U], kg_u4 (&xv)[KG_U], int lrg, int lt) {
+        issue_x(xv, lrg, lt);
+        issue_w(wv, lrg, lt);
+    };
+
+    // two batches of weight tiles in flight while the prologue finishes
+    int lrg = rg, lt = t0;
+    if (EARLY) issue_x(bufAx, lrg, lt);
+    else issue(bufA, bufAx, lrg, lt);
+    lt += KG_U;
+    if (lt >= t1) { lt = t0; lrg += gridDim.x; }
+    if (EARLY) issue_x(bufBx, lrg, lt);
+    else issue(bufB, bufBx, lrg, lt);
+    lt += KG_U;
+    if (lt >= t1) { lt = t0; lrg += gridDim.x; }
+
+    if (side_fast) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = tid + e * nthreads;
+            if (i < side_n) {
+                if (EPI == EPI_RESID) ((unsigned short*)side)[i] = (unsigned short)side_raw[e];
+                if (EPI == EPI_ROPE_KV) ((unsigned*)side)[i] = side_raw[e];
+            }
+        }
+    }
+    if (MODE != MODE_MFMA_GX && pro_fast) prologue_finish<DT, PRO, RM>(a, pr, xs, xs_stride, ss, M, tid);
+    __syncthreads();
+
+    HeadRun run; run.mx = -INFINITY; run.sum = 0.f; run.idx = 0;
+    float rstd = 1.f;
+    int it = 0, ct = t0;
+    kg_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    float acc0 = 0.f, acc1 = 0.f;
+
+    // One step: consume the batch held in (wv, xv), refill the same registers with the batch
+    // two ahead (the two buffers alternate, so no register copies and up to 2*KG_U tiles stay
+    // in flight per wave), and at the end of a row group reduce across waves and run the
+    // epilogue.
+    auto step = [&](kg_u4 (&wv)[KG_U], kg_u4 (&xv)[KG_U], int which) {
+        char* xslot = xs + (size_t)(wave * 2 + which) * a.gx_slot_rows * GX_ROW;      // MODE_MFMA_GX only
+        if (MODE == MODE_MFMA_GX) {
+#pragma unroll
+            for (int j = 0; j < KG_U; ++j) {
+                const int flat = j * 64 + lane, row = flat >> 5, ch = flat & 31;
+                if (row < a.gx_slot_rows) *(kg_u4*)(xslot + row * GX_ROW + ch * 16) = xv[j];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < KG_U; ++u) {
+            const kg_u4 w = wv[u];                    // zeros when the tile was out of range
+            const int tt = min(ct + u, tlast);
+            if (MODE == MODE_VEC) {
+                kg_u4 x = *(const kg_u4*)(xl + (size_t)tt * 64);
+                acc0 = T::dot2(w.x, x.x, acc0);
+                acc1 = T::dot2(w.y, x.y, acc1);
+                acc0 = T::dot2(w.z, x.z, acc0);
+                acc1 = T::dot2(w.w, x.w, acc1);
+            } else if (MODE == MODE_MFMA) {
+                kg_u4 x = *(const kg_u4*)(xl + (size_t)tt * 64);
+                acc = T::mfma(w, x, acc);
+            } else {
+                kg_u4 x = *(const kg_u4*)(xslot + mrow * GX_ROW + u * 64 + g * 16);
+                acc = T::mfma(w, x, acc);
+            }
+        }
+        issue(wv, xv, lrg, lt);
+        lt += KG_U;
+        if (lt >= t1) { lt = t0; lrg += gridDim.x; }
+        ct += KG_U;
+        if (ct >= t1 && rg < G) {
+            // ---- cross-wave reduction through LDS (slot alternates per row group) ----
+            float* slot = part + (size_t)(it & 1) * nwaves * PART;
+            if (MODE == MODE_VEC) {
+                float v = acc0 + acc1;
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (lane < 16) slot[wave * 16 + lane] = v;
+            } else {
+                // lane holds D[row 4g+i][col r]; store as [col][row] so a pair reads 2 floats
+                *(kg_f4*)(slot + wave * 256 + r * 16 + g * 4) = acc;
+            }
+            if (PRO == PRO_RMSNORM && it == 0) {
+#pragma unroll
+                for (int m = 0; m < RM; ++m) {
+                    if (m < M) {
+                        const float t = kg_wave_sum(ss[m]);
+                        if (lane == 0) red2[m * nwaves + wave] = t;
+                    }
+                }
+            }
+            __syncthreads();
+            const int n_epi = (MODE == MODE_VEC) ? 8 : 128;
+            if (tid < n_epi) {
+                const int m = tid >> 3, p = tid & 7;
+                if (m < M) {
+                    if (PRO == PRO_RMSNORM && it == 0) {
+                        float tot = 0.f;
+                        for (int w = 0; w < nwaves; ++w) tot += red2[m * nwaves + w];
+                        rstd = rsqrtf(tot / (float)a.K + a.eps);
+                    }
+                    float v0 = 0.f, v1 = 0.f;
+                    for (int w = 0; w < nwaves; ++w) {
+                        const float* sp = slot + w * PART + m * 16 + 2 * p;
+                        v0 += sp[0]; v1 += sp[1];
+                    }
+                    if (PRO == PRO_RMSNORM) { v0 *= rstd; v1 *= rstd; }
+                    epilogue_pair<DT, EPI, COH>(a, rg * 16 + 2 * p, m, my_pos, v0, v1, run, side, it, M);
+                }
+            }
+            rg += gridDim.x; ct = t0; ++it;
+            acc = kg_f4{0.f, 0.f, 0.f, 0.f}; acc0 = 0.f; acc1 = 0.f;
+        }
+    };
+    // Steps come in pairs with a single back edge, so that at the top of the loop the other
+    // buffer's refill is always "newer" and the counted waits keep it in flight.  A trailing
+    // step past the last row group only sees out-of-range (zero) tiles and skips the epilogue.
+    do {
+        step(bufA, bufAx, 0);
+        step(bufB, bufBx, 1);
+    } while (rg < G);
+    if (EPI == EPI_HEAD) {
+        // merge the 8 pair-threads of each column, then one record per (block, column)
+        const int n_epi = (MODE == MODE_VEC) ? 8 : 128;
+        if (tid < 128) {      // whole waves take part in the shuffles
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                float bmx = __shfl_xor(run.mx, o, 64);
+                float bs = __shfl_xor(run.sum, o, 64);
+                int bi = __shfl_xor(run.idx, o, 64);
+                head_merge(run, bmx, bs, bi);
+            }
+            const int m = tid >> 3;
+            if (tid < n_epi && (tid & 7) == 0 && m < M && (int)blockIdx.x < G) {     // blocks without a row group have no record
+                float* hp = a.head_part + ((size_t)m * a.head_part_stride + blockIdx.x) * 4;
+                hp[0] = run.mx; hp[1] = run.sum; hp[2] = __int_as_float(run.idx); hp[3] = 0.f;
+            }
+        }
+    }
+    if (PERSIST) gb->arrive();
+}

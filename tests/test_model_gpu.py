@@ -216,3 +216,35 @@ def test_error_conventions_and_bounds():
     assert new_tok <= 40 and new_tok >= 40 - 1 - 6
     out1, new1, _, acc1 = kangaroo_forward(ids, model, -1, 1)            # no round fits: only the prefill token
     assert new1 == 1 and acc1 == [1] and len(out1[0]) == ids.shape[1] + 1
+
+
+@pytest.mark.parametrize("shape_name,dtype", [("small", torch.float16), ("tinyllama-1.1b", torch.float16), ("small", torch.bfloat16)])
+def test_persistent_pass_is_bit_identical_to_kernel_by_kernel(shape_name, dtype):
+    """The verify pass / deep layers can run as one persistent kernel (tuning key "persist" = 2,
+    shapes with head_dim >= 32) instead of one kernel per op.  Same arithmetic, same summation
+    order: tokens, accept lengths and draft lengths must agree exactly."""
+    shape = get_shape(shape_name)
+    if shape_name == "tinyllama-1.1b":
+        shape = type(shape)(**{**shape.to_dict(), "num_hidden_layers": 4})
+    base, adapter = synth_state_dicts(shape, 2, seed=31, dtype=dtype, recipe=Recipe.agreeable(0.3, 8.0))
+    model = KangarooModel.from_state_dicts(shape, base, adapter, dtype, 2)
+    eng = model.engine
+    eng.set_tuning(persist=2)
+    assert eng.get_tuning("persist") == 1, "persistent passes should be available for this shape"
+    # the K split across a block's waves fixes the summation order: compare like with like
+    for op in ("qkv", "o", "gateup", "down", "head"):
+        eng.set_tuning(**{f"persist.{op}.waves": eng.get_tuning(f"mfma.{op}.waves")})
+    g = torch.Generator().manual_seed(5)
+    for plen in (5, 33, 150):
+        ids = torch.randint(3, shape.vocab_size, (1, plen), generator=g).cuda()
+        eng.set_tuning(persist=2)
+        on = kangaroo_forward(ids, model, -1, 96, return_stats=True)
+        van_on = vanilla_forward(ids, model, -1, 40)[0][0]
+        eng.set_tuning(persist=1)
+        assert eng.get_tuning("persist") == 0
+        off = kangaroo_forward(ids, model, -1, 96, return_stats=True)
+        van_off = vanilla_forward(ids, model, -1, 40)[0][0]
+        assert on[0][0] == off[0][0] and on[3] == off[3] and on[4].draft_lengths == off[4].draft_lengths
+        assert van_on == van_off
+        assert van_on == on[0][0][:len(van_on)]
+    eng.set_tuning(persist=2)
