@@ -133,7 +133,8 @@ int kg_session_destroy(kg_session* s);
 /* kg_session_get: "v_transposed" (layout of buffers.v_cache / av_cache the session expects:
  * 1 when head_dim >= 32 and t_max % 32 == 0), "prefill_rows", or a tuning key; -1 if unknown. */
 int kg_session_get(kg_session* s, const char* key);
-/* tuning knobs: "attn_nsplit" (fixes the split boundaries of the attention reduction);
+/* tuning knobs: "attn_nsplit" (number of fixed key chunks: fixes the boundaries of the attention
+ * reduction), "attn_blocks" (blocks that share one head's chunks; geometry only);
  * "<mode>_waves" and "<mode>_blocks_per_cu" for all linear ops of a mode, or "<mode>.<op>.waves" /
  * "<mode>.<op>.blocks_per_cu" for one, with mode in {vec (1 row), mfma (2..16 rows)} and op in
  * {qkv, o, gateup, down, head}; "persist" (2: run the verify pass and the deep layers of plain

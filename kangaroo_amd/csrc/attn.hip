@@ -15,6 +15,7 @@
 #include "kg_attn_body.h"
 
 #define ATT_U 4         // K and V loads in flight per lane per batch
+#define KG_ATTN_DYN_LDS (120 * 1024)   // dynamic LDS the MFMA kernel may ask for, beside its static team buffers
 
 // Called by every thread of a block after its partial stores.  Returns true in all threads
 // of the block that completed the head's set of n_act partials (and re-arms the counter).
@@ -187,22 +188,133 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_kernel(const KgAttnArgs a
 }
 
 // ---------------------------------------------------------------------------------
-// MFMA variant (head_dim 32 / 64 / 128, V cached transposed [Hkv][hd][t_max]): one block =
-// one team on one (query head, T-split); the work itself is kg_attn_mfma_item.
+// MFMA variant (head_dim 32 / 64 / 128, V cached transposed [Hkv][hd][t_max]).
+//
+// The keys are cut into fixed chunks (boundaries depend on t_max and nsplit only); a chunk is
+// worked on by the 4 waves of a block (32-key tiles, wave w takes tiles w, w+4, ...), whose
+// results meet in LDS: that gives one partial (max, sum, acc) per chunk and query row, and
+// the final rows are the merge of the chunk partials in chunk order.  This arithmetic is the
+// same however the chunks are spread over blocks.  A block owns `cpb` consecutive chunks of
+// one head and walks them with the next tile's K/V already requested while the current one
+// is computed.  If the chunks in use fit one block (contexts up to cpb * chunk keys) their
+// partials stay in LDS and the block writes the final rows itself: no global partials, no
+// counter, no second round trip.  Otherwise the partials go to memory and the block that
+// arrives last at the head's counter merges them.
 template <int DT, int HD>
 __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnArgs a) {
+    typedef KgT<DT> T;
     const KgDyn* dyn = a.dyn;
-    const int pos_c = dyn->pos[threadIdx.x & 15];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int pos_c = dyn->pos[c];
     if (dyn->active == 0) return;
     const int M = dyn->n_rows;
     const int len = dyn->pos[0] + M;               // rows of a pass sit at consecutive positions
-    const int nsplit = gridDim.y;
-    int chunk = (a.t_max + nsplit - 1) / nsplit;   // fixed split boundaries (see kg_attn_kernel)
+    const int h = blockIdx.x;
+    int chunk = (a.t_max + a.nsplit - 1) / a.nsplit;
     chunk = (chunk + 31) / 32 * 32;
-    const int n_act = (len + chunk - 1) / chunk;   // splits that hold keys; the others do nothing
-    if ((int)blockIdx.y >= n_act) return;
+    const int n_act = (len + chunk - 1) / chunk;   // chunks that hold keys
+    const int cpb = (a.nsplit + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int c0 = blockIdx.y * cpb, c1 = min(n_act, c0 + cpb);
+    if (c0 >= n_act) return;
+    const int nblk_act = (n_act + cpb - 1) / cpb;  // blocks of this head that have chunks
+    const bool local = (nblk_act == 1);
+
+    constexpr int KS = HD / 32, DB = HD / 16;
     __shared__ KgAttnTeamLds<HD> lds;
-    kg_attn_mfma_item<DT, HD, false>(a, true, blockIdx.x, blockIdx.y, n_act, chunk, M, len, pos_c, threadIdx.x, lds);
+    extern __shared__ __attribute__((aligned(16))) float pl[];      // local partials: [cpb][M][HD] then [cpb][M][2]
+    float* pl_o = pl;
+    float* pl_ml = pl + (size_t)cpb * M * HD;
+
+    const int kvh = h / (a.H / a.Hkv);
+    const int lim = (c < M) ? pos_c : -1;          // causal bound of this lane's query column
+    const __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc((void*)a.q, 0, (int)((size_t)M * a.H * HD * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned short*)a.k_cache + (size_t)kvh * a.t_max * HD), 0,
+                                                                        (int)((size_t)a.t_max * HD * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned short*)a.v_cache + (size_t)kvh * HD * a.t_max), 0,
+                                                                        (int)((size_t)a.t_max * HD * 2), 0x00020000);
+    kg_u4 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)       // rows >= M are out of range: zeros
+        qf[s] = __builtin_amdgcn_raw_buffer_load_b128(qr, (unsigned)((((size_t)c * a.H + h) * HD + 32 * s + 8 * g) * 2), 0, 0);
+    const float inv_scale = sqrtf((float)HD);
+
+    // prefetch cursor over this wave's tiles: (chunk pc, first key ptb)
+    int pc = c0, ptb = c0 * chunk + 32 * wave;
+    auto settle = [&]() {
+        while (pc < c1 && ptb >= min(len, pc * chunk + chunk)) { ++pc; ptb = pc * chunk + 32 * wave; }
+    };
+    settle();
+    KgAttnTile<HD> nxt;
+    if (pc < c1) attn_tile_load<HD, 0>(nxt, kr, vr, a.t_max, ptb, lane);
+
+    for (int ch = c0; ch < c1; ++ch) {
+        const int tbeg = ch * chunk, tend = min(len, tbeg + chunk);
+        float mrun = -INFINITY, lsum = 0.f;
+        kg_f4 O[DB];
+#pragma unroll
+        for (int b = 0; b < DB; ++b) O[b] = kg_f4{0.f, 0.f, 0.f, 0.f};
+        for (int tb = tbeg + 32 * wave; tb < tend; tb += 32 * ATT_NW) {
+            const KgAttnTile<HD> cur = nxt;        // == tile (ch, tb): the cursor visits tiles in this order
+            ptb += 32 * ATT_NW;
+            settle();
+            if (pc < c1) attn_tile_load<HD, 0>(nxt, kr, vr, a.t_max, ptb, lane);
+            attn_tile_compute<DT, HD>(cur, qf, tb, tend, lim, inv_scale, lane, mrun, lsum, O);
+        }
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        // ---- merge the waves of this chunk through LDS ----
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lds.o[wave][4 * g + i][16 * b + c] = O[b][i];
+        if (g == 0) { lds.ml[wave][c][0] = mrun; lds.ml[wave][c][1] = lsum; }
+        __syncthreads();
+        for (int i = tid; i < M * HD; i += ATT_NW * 64) {
+            const int m = i / HD, dmi = i - m * HD;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < ATT_NW; ++w) mx = fmaxf(mx, lds.ml[w][m][0]);
+            float o = 0.f, l = 0.f;
+#pragma unroll
+            for (int w = 0; w < ATT_NW; ++w) {
+                const float wm = lds.ml[w][m][0];
+                const float fw = (wm == -INFINITY) ? 0.f : expf(wm - mx);
+                o += fw * lds.o[w][m][dmi];
+                l += fw * lds.ml[w][m][1];
+            }
+            if (local) {
+                pl_o[((size_t)(ch - c0) * M + m) * HD + dmi] = o;
+                if (dmi == 0) { pl_ml[((ch - c0) * M + m) * 2] = mx; pl_ml[((ch - c0) * M + m) * 2 + 1] = l; }
+            } else {
+                coh_store(a.part_o + (((size_t)ch * a.max_rows + m) * a.H + h) * HD + dmi, o);
+                if (dmi == 0) {
+                    float* ml = a.part_ml + (((size_t)ch * a.max_rows + m) * a.H + h) * 2;
+                    coh_store(ml, mx); coh_store(ml + 1, l);
+                }
+            }
+        }
+        __syncthreads();                           // lds is free for the next chunk; local partials are visible
+    }
+    if (local) {
+        // same merge as split_combine, partials read from LDS
+        const int ns = c1 - c0;
+        for (int i = tid; i < M * HD; i += ATT_NW * 64) {
+            const int m = i / HD, dmi = i - m * HD;
+            float mx = -INFINITY;
+            for (int s = 0; s < ns; ++s) mx = fmaxf(mx, pl_ml[(s * M + m) * 2]);
+            float o = 0.f, l = 0.f;
+            for (int s = 0; s < ns; ++s) {
+                const float m_s = pl_ml[(s * M + m) * 2];
+                const float f = (m_s == -INFINITY) ? 0.f : expf(m_s - mx);
+                o += f * pl_o[((size_t)s * M + m) * HD + dmi];
+                l += f * pl_ml[(s * M + m) * 2 + 1];
+            }
+            ((unsigned short*)a.out)[((size_t)m * a.H + h) * HD + dmi] = T::from_f(o / l);
+        }
+        return;
+    }
+    if (split_arrive(a.counters + h, nblk_act)) split_combine<DT, false>(a, h, HD, 0, M, n_act, tid, ATT_NW * 64);
 }
 
 template <int DT, int LPR>
@@ -218,11 +330,15 @@ static void launch_lpr(const KgAttnArgs& a, hipStream_t st) {
 template <int DT>
 static int launch_dt(const KgAttnArgs& a, hipStream_t st) {
     if (a.v_transposed) {
-        dim3 grid(a.H, a.nsplit, 1);
+        const int nby = a.blocks_per_head < 1 ? 1 : (a.blocks_per_head > a.nsplit ? a.nsplit : a.blocks_per_head);
+        const int cpb = (a.nsplit + nby - 1) / nby;
+        dim3 grid(a.H, nby, 1);
+        const size_t smem = (size_t)cpb * a.max_rows * (a.hd + 2) * sizeof(float);
+        if (smem > (size_t)KG_ATTN_DYN_LDS) return -1;
         switch (a.hd) {
-        case 32: hipLaunchKernelGGL((kg_attn_mfma_kernel<DT, 32>), grid, dim3(ATT_NW * 64), 0, st, a); break;
-        case 64: hipLaunchKernelGGL((kg_attn_mfma_kernel<DT, 64>), grid, dim3(ATT_NW * 64), 0, st, a); break;
-        case 128: hipLaunchKernelGGL((kg_attn_mfma_kernel<DT, 128>), grid, dim3(ATT_NW * 64), 0, st, a); break;
+        case 32: hipLaunchKernelGGL((kg_attn_mfma_kernel<DT, 32>), grid, dim3(ATT_NW * 64), smem, st, a); break;
+        case 64: hipLaunchKernelGGL((kg_attn_mfma_kernel<DT, 64>), grid, dim3(ATT_NW * 64), smem, st, a); break;
+        case 128: hipLaunchKernelGGL((kg_attn_mfma_kernel<DT, 128>), grid, dim3(ATT_NW * 64), smem, st, a); break;
         default: return -1;
         }
     } else {
@@ -235,6 +351,18 @@ static int launch_dt(const KgAttnArgs& a, hipStream_t st) {
         }
     }
     return 0;
+}
+
+// One-time opt-in for > 64 KiB of LDS (team buffers + local chunk partials of 16-row passes).
+void kg_attn_init() {
+    const int lim = KG_ATTN_DYN_LDS;
+    (void)hipFuncSetAttribute((const void*)kg_attn_mfma_kernel<KG_F16, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_attn_mfma_kernel<KG_F16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_attn_mfma_kernel<KG_F16, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_attn_mfma_kernel<KG_BF16, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_attn_mfma_kernel<KG_BF16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_attn_mfma_kernel<KG_BF16, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipGetLastError();
 }
 
 int kg_launch_attn(const KgAttnArgs& a, int dtype, hipStream_t st) {

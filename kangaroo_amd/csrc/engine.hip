@@ -23,6 +23,7 @@ static int g_ncu = 256;
 static void kg_init_once() {
     if (g_init) return;
     kg_linear_init();
+    kg_attn_init();
     int dev = 0;
     hipDeviceProp_t p;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_ncu = p.multiProcessorCount;
@@ -51,7 +52,7 @@ struct kg_session {
     // tuning
     // launch geometry per (mode: 0 GEMV / 1 MFMA, op: qkv, o, gateup, down, head)
     int waves[2][5], bpc[2][5];
-    int attn_nsplit;
+    int attn_nsplit, attn_blocks;
     int v_transposed;
     // persistent pass kernel: phase programs [0] verify pass, [1] deep layers of plain decoding
     int persist;                       // 1: multi-row passes of the loop run as one persistent kernel
@@ -159,6 +160,7 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     s->waves[1][3] = 2;                          // down_proj in the large-K MFMA mode
     s->v_transposed = (shape->head_dim >= 32 && buffers->t_max % 32 == 0) ? 1 : 0;
     s->attn_nsplit = 16;
+    s->attn_blocks = 16;                         // one chunk per block: long contexts need many CUs pulling K/V (one CU sustains only ~60 GB/s)
     s->round_graph = nullptr; s->round_graph_steps = -1; s->vanilla_graph = nullptr;
     s->prog_n[0] = s->prog_n[1] = s->prog_n[2] = 0;
     for (int op = 0; op < 5; ++op) s->persist_waves[op] = 8;
@@ -199,6 +201,7 @@ extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
     if (value < 1) return fail(-1, "value must be >= 1");
     bool done = false;
     if (k == "attn_nsplit") { if (value > 32) return fail(-1, "nsplit <= 32"); s->attn_nsplit = value; done = true; }
+    if (k == "attn_blocks") { if (value > 32) return fail(-1, "attn_blocks <= 32"); s->attn_blocks = value; done = true; }
     if (k == "persist") { s->persist = (value >= 2 && s->v_transposed && (g_ncu % 8) == 0) ? 1 : 0; done = true; }   // 1: off, 2: on
     for (int op = 0; op < 5 && !done; ++op)
         if (k == std::string("persist.") + kg_op_names[op] + ".waves") { if (value > 8) return fail(-1, "waves <= 8"); s->persist_waves[op] = value; done = true; }
@@ -231,6 +234,7 @@ extern "C" int kg_session_get(kg_session* s, const char* key) {
         }
     }
     if (k == "attn_nsplit") return s->attn_nsplit;
+    if (k == "attn_blocks") return s->attn_blocks;
     if (k == "persist") return s->persist;
     if (k == "prefill_rows") return s->prefill_rows;
     return -1;
@@ -283,7 +287,7 @@ static int run_layer(kg_session* s, const kg_layer_weights& lw, void* kc, void* 
         memset(&a, 0, sizeof(a));
         a.dyn = dyn; a.q = s->xq; a.k_cache = kc; a.v_cache = vc;
         a.H = sh.num_heads; a.Hkv = sh.num_kv_heads; a.hd = sh.head_dim; a.t_max = s->buf.t_max; a.v_transposed = s->v_transposed;
-        a.nsplit = s->attn_nsplit; a.part_o = s->part_o; a.part_ml = s->part_ml; a.counters = s->attn_counters; a.out = s->attn_out; a.max_rows = max_rows;
+        a.nsplit = s->attn_nsplit; a.blocks_per_head = s->attn_blocks; a.part_o = s->part_o; a.part_ml = s->part_ml; a.counters = s->attn_counters; a.out = s->attn_out; a.max_rows = max_rows;
         KG_TRY(kg_launch_attn(a, dt, st));
     }
     const bool attn_only = (lw.wgu == nullptr);
@@ -476,7 +480,7 @@ static int build_program(kg_session* s, int which, const KgDyn* dyn, int max_row
             KgAttnArgs& a = p.attn;
             a.dyn = dyn; a.q = xq; a.k_cache = layer_k(s, l); a.v_cache = layer_v(s, l);
             a.H = sh.num_heads; a.Hkv = sh.num_kv_heads; a.hd = sh.head_dim; a.t_max = s->buf.t_max; a.v_transposed = 1;
-            a.nsplit = s->attn_nsplit; a.part_o = s->part_o; a.part_ml = s->part_ml; a.counters = s->attn_counters; a.out = ao; a.max_rows = max_rows;
+            a.nsplit = s->attn_nsplit; a.blocks_per_head = s->attn_blocks; a.part_o = s->part_o; a.part_ml = s->part_ml; a.counters = s->attn_counters; a.out = ao; a.max_rows = max_rows;
             prog.push_back(p);
         }
         {
@@ -893,7 +897,7 @@ extern "C" int kg_attention(int dtype, const void* q, int n_rows, int pos0, cons
     KgAttnArgs a;
     memset(&a, 0, sizeof(a));
     a.dyn = dyn; a.q = q; a.k_cache = k_cache; a.v_cache = v_cache; a.H = n_heads; a.Hkv = n_kv_heads; a.hd = head_dim; a.t_max = t_max; a.v_transposed = v_transposed ? 1 : 0;
-    a.nsplit = nsplit; a.max_rows = n_rows;
+    a.nsplit = nsplit; a.blocks_per_head = nsplit; a.max_rows = n_rows;
     a.part_o = (float*)((char*)scratch + 256);
     a.part_ml = a.part_o + (size_t)nsplit * KG_MAX_ROWS * n_heads * head_dim;
     a.counters = (unsigned*)(((uintptr_t)(a.part_ml + (size_t)nsplit * KG_MAX_ROWS * n_heads * 2) + 255) & ~(uintptr_t)255);

@@ -51,6 +51,81 @@ template <int HD> struct KgAttnTeamLds {
     int last;
 };
 
+// One 32-key tile of one wave: K rows as A fragments of the two score MFMAs, V^T pieces as B
+// fragments of the P.V MFMAs.
+template <int HD> struct KgAttnTile {
+    kg_u4 kf[2][HD / 32];
+    kg_u4 vf[HD / 16];
+};
+
+template <int HD, int AUX>
+__device__ __forceinline__ void attn_tile_load(KgAttnTile<HD>& t, const __amdgpu_buffer_rsrc_t& kr, const __amdgpu_buffer_rsrc_t& vr,
+                                               int t_max, int tb, int lane) {
+    const int c = lane & 15, g = lane >> 4;
+    const int krow = 8 * (c >> 2) + (c & 3);       // tile 0: MFMA row c <-> key tb + krow; tile 1: + 4
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int s = 0; s < HD / 32; ++s)
+            t.kf[tt][s] = __builtin_amdgcn_raw_buffer_load_b128(kr, (unsigned)(((size_t)(tb + krow + 4 * tt) * HD + 32 * s + 8 * g) * 2), 0, AUX);
+#pragma unroll
+    for (int b = 0; b < HD / 16; ++b)
+        t.vf[b] = __builtin_amdgcn_raw_buffer_load_b128(vr, (unsigned)(((size_t)(16 * b + c) * t_max + tb + 8 * g) * 2), 0, AUX);
+}
+
+// scores, online softmax and P.V of one tile; (mrun, lsum, O) are the wave's running state
+template <int DT, int HD>
+__device__ __forceinline__ void attn_tile_compute(const KgAttnTile<HD>& t, const kg_u4 (&qf)[HD / 32], int tb, int tend, int lim,
+                                                  float inv_scale, int lane, float& mrun, float& lsum, kg_f4 (&O)[HD / 16]) {
+    typedef KgT<DT> T;
+    constexpr int KS = HD / 32, DB = HD / 16;
+    const int g = lane >> 4;
+    float sc[8];
+    float bm = -INFINITY;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        kg_f4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) d = T::mfma(t.kf[tt][s], qf[s], d);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = tb + 8 * g + 4 * tt + i;
+            // reference op boundaries: q.k^T stored, then divided by sqrt(hd) and stored
+            const float v = kg_round<DT>(kg_round<DT>(d[i]) / inv_scale);
+            sc[4 * tt + i] = (key < tend && key <= lim) ? v : -INFINITY;
+            bm = fmaxf(bm, sc[4 * tt + i]);
+        }
+    }
+    bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+    const float mnew = fmaxf(mrun, bm);
+    const float scale = (mrun == -INFINITY) ? 0.f : expf(mrun - mnew);     // mnew == -inf only if mrun is too
+    unsigned short ph[8];
+    float psum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float p = (sc[j] == -INFINITY) ? 0.f : expf(sc[j] - mnew);
+        psum += p;
+        ph[j] = T::from_f(p);
+    }
+    lsum = lsum * scale + psum;
+    mrun = mnew;
+    kg_u4 pf;
+    pf.x = ph[0] | ((unsigned)ph[1] << 16); pf.y = ph[2] | ((unsigned)ph[3] << 16);
+    pf.z = ph[4] | ((unsigned)ph[5] << 16); pf.w = ph[6] | ((unsigned)ph[7] << 16);
+    // accumulator rows are query rows 4g..4g+3: fetch their rescale factors from the
+    // lanes of this 16-lane group that own those columns
+    float f[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __shfl(scale, (lane & 48) | (4 * g + i), 64);
+#pragma unroll
+    for (int b = 0; b < DB; ++b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) O[b][i] *= f[i];
+        O[b] = T::mfma(pf, t.vf[b], O[b]);
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // Per wave and 32 keys:  S^T = K q^T  as two 16-key tiles of v_mfma_f32_16x16x32 (A = K rows,
 // B = q^T, so every lane owns one query column and 8 keys), softmax statistics per column
@@ -93,62 +168,11 @@ __device__ __forceinline__ void kg_attn_mfma_item(const KgAttnArgs& a, bool vali
 #pragma unroll
         for (int b = 0; b < DB; ++b) O[b] = kg_f4{0.f, 0.f, 0.f, 0.f};
         const float inv_scale = sqrtf((float)HD);
-        const int krow = 8 * (c >> 2) + (c & 3);       // tile 0: MFMA row c <-> key tb + krow; tile 1: + 4
 
         for (int tb = tbeg + 32 * wave; tb < tend; tb += 32 * ATT_NW) {
-            kg_u4 kf[2][KS], vf[DB];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int s = 0; s < KS; ++s)
-                    kf[t][s] = __builtin_amdgcn_raw_buffer_load_b128(kr, (unsigned)(((size_t)(tb + krow + 4 * t) * HD + 32 * s + 8 * g) * 2), 0, AUX);
-#pragma unroll
-            for (int b = 0; b < DB; ++b)
-                vf[b] = __builtin_amdgcn_raw_buffer_load_b128(vr, (unsigned)(((size_t)(16 * b + c) * a.t_max + tb + 8 * g) * 2), 0, AUX);
-            float sc[8];
-            float bm = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                kg_f4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < KS; ++s) d = T::mfma(kf[t][s], qf[s], d);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int key = tb + 8 * g + 4 * t + i;
-                    // reference op boundaries: q.k^T stored, then divided by sqrt(hd) and stored
-                    const float v = kg_round<DT>(kg_round<DT>(d[i]) / inv_scale);
-                    sc[4 * t + i] = (key < tend && key <= lim) ? v : -INFINITY;
-                    bm = fmaxf(bm, sc[4 * t + i]);
-                }
-            }
-            bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-            bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-            const float mnew = fmaxf(mrun, bm);
-            const float scale = (mrun == -INFINITY) ? 0.f : expf(mrun - mnew);     // mnew == -inf only if mrun is too
-            unsigned short ph[8];
-            float psum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float p = (sc[j] == -INFINITY) ? 0.f : expf(sc[j] - mnew);
-                psum += p;
-                ph[j] = T::from_f(p);
-            }
-            lsum = lsum * scale + psum;
-            mrun = mnew;
-            kg_u4 pf;
-            pf.x = ph[0] | ((unsigned)ph[1] << 16); pf.y = ph[2] | ((unsigned)ph[3] << 16);
-            pf.z = ph[4] | ((unsigned)ph[5] << 16); pf.w = ph[6] | ((unsigned)ph[7] << 16);
-            // accumulator rows are query rows 4g..4g+3: fetch their rescale factors from the
-            // lanes of this 16-lane group that own those columns
-            float f[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) f[i] = __shfl(scale, (lane & 48) | (4 * g + i), 64);
-#pragma unroll
-            for (int b = 0; b < DB; ++b) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) O[b][i] *= f[i];
-                O[b] = T::mfma(pf, vf[b], O[b]);
-            }
+            KgAttnTile<HD> t;
+            attn_tile_load<HD, AUX>(t, kr, vr, a.t_max, tb, lane);
+            attn_tile_compute<DT, HD>(t, qf, tb, tend, lim, inv_scale, lane, mrun, lsum, O);
         }
         lsum += __shfl_xor(lsum, 16, 64);
         lsum += __shfl_xor(lsum, 32, 64);

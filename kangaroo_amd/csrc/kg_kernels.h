@@ -39,7 +39,8 @@ struct KgAttnArgs {
     const void* v_cache;
     int H, Hkv, hd, t_max;
     int v_transposed;           // 1: v_cache is [Hkv, hd, t_max] and the MFMA kernel runs (hd 32/64/128, t_max % 32 == 0)
-    int nsplit;
+    int nsplit;                 // number of fixed key chunks the cache is cut into
+    int blocks_per_head;        // MFMA kernel: blocks that share the chunks of one head (launch geometry only)
     float* part_o;              // [nsplit][rows][H][hd]
     float* part_ml;             // [nsplit][rows][H][2]
     unsigned* counters;         // [2][H] arrival counters of the split merge; zero between launches
@@ -47,6 +48,7 @@ struct KgAttnArgs {
     int max_rows;
 };
 int kg_launch_attn(const KgAttnArgs& a, int dtype, hipStream_t st);
+void kg_attn_init();
 
 // persistent pass kernel: a list of phases walked by resident blocks (see persist.hip)
 enum { KG_PH_QKV = 0, KG_PH_ATTN = 1, KG_PH_O = 2, KG_PH_GATEUP = 3, KG_PH_DOWN = 4, KG_PH_DOWN_GX = 5, KG_PH_HEAD = 6 };
