@@ -160,8 +160,15 @@ def main():
     rows = a.spec_steps + 1
     us, wbytes = eng.bench_op("gateup", rows, iters=4 * shape.num_hidden_layers)
     ach = wbytes / (us * 1e-6) / 1e9
+    # HBM bytes per launch from the PMC passes over this same kernel and shape (counters need runs of
+    # their own; profiles/r01_pmc_gateup_rows7.json records command, raw counters and the gfx950 correction)
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_gateup_rows7.json")
+    if a.model == "vicuna-7b" and rows == 7 and os.path.exists(pmc_file):
+        with open(pmc_file) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": "kg_linear_kernel<f16, MFMA, RMSNorm, SiLU*mul> (gate/up projection of the verify pass)",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "us_per_launch": us, "algorithmic_bytes_per_launch": wbytes}
     per_kernel = {}
     for op in ("qkv", "o", "gateup", "down", "head"):

@@ -12,7 +12,7 @@
 #define KG_AUX_COH 16
 #endif
 #ifndef KG_PERSIST_COH_LOADS
-#define KG_PERSIST_COH_LOADS 0
+#define KG_PERSIST_COH_LOADS 1
 #endif
 
 // Device-coherent access to the split partials: these bypass the per-XCD L2, so a block on

@@ -36,12 +36,13 @@ enum { MODE_VEC = 0, MODE_MFMA = 1, MODE_MFMA_GX = 2 };
 #ifndef KG_AUX_COH
 #define KG_AUX_COH 16           // buffer-load cache policy: sc1 (agent scope)
 #endif
-// Persistent passes give every layer its own activation buffers, so a line is written (through
-// to memory) once per launch and only read afterwards: ordinary cached loads then cannot see a
-// stale copy, and the rows are fetched from memory once per XCD instead of once per block.
-// 1 = read them device-coherently anyway (needed if buffers were reused within a launch).
+// Persistent passes: what another block wrote earlier in the same launch is read with
+// device-coherent (sc1) loads, the counterpart of the sc1 stores.  Every layer also has its own
+// activation buffers, so a line is written once per launch and only read afterwards; with that,
+// ordinary cached loads (0) gave identical results in all tests here and fetch the rows once per
+// XCD instead of once per block, but only the sc1/sc1 pairing is a documented hand-off.
 #ifndef KG_PERSIST_COH_LOADS
-#define KG_PERSIST_COH_LOADS 0
+#define KG_PERSIST_COH_LOADS 1
 #endif
 template <bool COH> __device__ __forceinline__ void st16(unsigned short* p, unsigned short v) {
     if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, KG_AGENT);
