@@ -206,10 +206,15 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnA
     const KgDyn* dyn = a.dyn;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
-    const int pos_c = dyn->pos[c];
+    // blockIdx.z selects a block of 16 query rows (prefill passes carry up to KG_GEMM_ROWS rows);
+    // rows of a pass sit at consecutive positions
+    const int row0 = 16 * blockIdx.z;
+    const int pos_c = dyn->pos[0] + row0 + c;
     if (dyn->active == 0) return;
-    const int M = dyn->n_rows;
-    const int len = dyn->pos[0] + M;               // rows of a pass sit at consecutive positions
+    const int Mtot = dyn->n_rows;
+    if (row0 >= Mtot) return;
+    const int M = min(16, Mtot - row0);
+    const int len = dyn->pos[0] + row0 + M;
     const int h = blockIdx.x;
     int chunk = (a.t_max + a.nsplit - 1) / a.nsplit;
     chunk = (chunk + 31) / 32 * 32;
@@ -228,7 +233,7 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnA
 
     const int kvh = h / (a.H / a.Hkv);
     const int lim = (c < M) ? pos_c : -1;          // causal bound of this lane's query column
-    const __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc((void*)a.q, 0, (int)((size_t)M * a.H * HD * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc((void*)a.q, 0, (int)((size_t)(row0 + M) * a.H * HD * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned short*)a.k_cache + (size_t)kvh * a.t_max * HD), 0,
                                                                         (int)((size_t)a.t_max * HD * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned short*)a.v_cache + (size_t)kvh * HD * a.t_max), 0,
@@ -236,7 +241,7 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnA
     kg_u4 qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s)       // rows >= M are out of range: zeros
-        qf[s] = __builtin_amdgcn_raw_buffer_load_b128(qr, (unsigned)((((size_t)c * a.H + h) * HD + 32 * s + 8 * g) * 2), 0, 0);
+        qf[s] = __builtin_amdgcn_raw_buffer_load_b128(qr, (unsigned)((((size_t)(row0 + c) * a.H + h) * HD + 32 * s + 8 * g) * 2), 0, 0);
     const float inv_scale = sqrtf((float)HD);
 
     // prefetch cursor over this wave's tiles: (chunk pc, first key ptb)
@@ -287,9 +292,9 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnA
                 pl_o[((size_t)(ch - c0) * M + m) * HD + dmi] = o;
                 if (dmi == 0) { pl_ml[((ch - c0) * M + m) * 2] = mx; pl_ml[((ch - c0) * M + m) * 2 + 1] = l; }
             } else {
-                coh_store(a.part_o + (((size_t)ch * a.max_rows + m) * a.H + h) * HD + dmi, o);
+                coh_store(a.part_o + (((size_t)ch * a.max_rows + row0 + m) * a.H + h) * HD + dmi, o);
                 if (dmi == 0) {
-                    float* ml = a.part_ml + (((size_t)ch * a.max_rows + m) * a.H + h) * 2;
+                    float* ml = a.part_ml + (((size_t)ch * a.max_rows + row0 + m) * a.H + h) * 2;
                     coh_store(ml, mx); coh_store(ml + 1, l);
                 }
             }
@@ -310,11 +315,11 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnA
                 o += f * pl_o[((size_t)s * M + m) * HD + dmi];
                 l += f * pl_ml[(s * M + m) * 2 + 1];
             }
-            ((unsigned short*)a.out)[((size_t)m * a.H + h) * HD + dmi] = T::from_f(o / l);
+            ((unsigned short*)a.out)[((size_t)(row0 + m) * a.H + h) * HD + dmi] = T::from_f(o / l);
         }
         return;
     }
-    if (split_arrive(a.counters + h, nblk_act)) split_combine<DT, false>(a, h, HD, 0, M, n_act, tid, ATT_NW * 64);
+    if (split_arrive(a.counters + blockIdx.z * a.H + h, nblk_act)) split_combine<DT, false>(a, h, HD, row0, M, n_act, tid, ATT_NW * 64);
 }
 
 template <int DT, int LPR>
@@ -332,8 +337,8 @@ static int launch_dt(const KgAttnArgs& a, hipStream_t st) {
     if (a.v_transposed) {
         const int nby = a.blocks_per_head < 1 ? 1 : (a.blocks_per_head > a.nsplit ? a.nsplit : a.blocks_per_head);
         const int cpb = (a.nsplit + nby - 1) / nby;
-        dim3 grid(a.H, nby, 1);
-        const size_t smem = (size_t)cpb * a.max_rows * (a.hd + 2) * sizeof(float);
+        dim3 grid(a.H, nby, (a.max_rows + 15) / 16);
+        const size_t smem = (size_t)cpb * (a.max_rows < 16 ? a.max_rows : 16) * (a.hd + 2) * sizeof(float);
         if (smem > (size_t)KG_ATTN_DYN_LDS) return -1;
         switch (a.hd) {
         case 32: hipLaunchKernelGGL((kg_attn_mfma_kernel<DT, 32>), grid, dim3(ATT_NW * 64), smem, st, a); break;
@@ -366,7 +371,7 @@ void kg_attn_init() {
 }
 
 int kg_launch_attn(const KgAttnArgs& a, int dtype, hipStream_t st) {
-    if (!a.counters || a.nsplit < 1 || a.max_rows < 1 || a.max_rows > KG_MAX_ROWS || a.H % a.Hkv != 0) return -1;
+    if (!a.counters || a.nsplit < 1 || a.max_rows < 1 || a.max_rows > (a.v_transposed ? KG_GEMM_ROWS : KG_MAX_ROWS) || a.H % a.Hkv != 0) return -1;
     if (a.v_transposed && (a.t_max % 32 != 0)) return -1;
     int rc = (dtype == KG_F16) ? launch_dt<KG_F16>(a, st) : launch_dt<KG_BF16>(a, st);
     if (rc) return rc;

@@ -11,24 +11,24 @@ __global__ void kg_set_dyn_kernel(KgDyn* dyn, int active, int n_rows, int pos0) 
     if (i < KG_MAX_ROWS) dyn->pos[i] = pos0 + i;
 }
 int kg_launch_set_dyn(KgDyn* dyn, int active, int n_rows, int pos0, hipStream_t st) {
-    if (n_rows < 0 || n_rows > KG_MAX_ROWS) return -1;
+    if (n_rows < 0 || n_rows > KG_GEMM_ROWS) return -1;      // > KG_MAX_ROWS: prefill passes, which use pos[0] + m
     hipLaunchKernelGGL(kg_set_dyn_kernel, dim3(1), dim3(64), 0, st, dyn, active, n_rows, pos0);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-// out[m][:] = embed[tokens[pos[m]]][:]   (16-bit elements, d % 8 == 0)
+// out[m][:] = embed[tokens[pos[0] + m]][:]   (16-bit elements, d % 8 == 0; rows of a pass sit at consecutive positions)
 __global__ void kg_embed_kernel(const KgDyn* dyn, const int* tokens, const kg_u4* embed, int d8, kg_u4* out, int out_stride8) {
     if (dyn->active == 0) return;
     const int m = blockIdx.x;
     if (m >= dyn->n_rows) return;
-    const int tok = tokens[dyn->pos[m]];
+    const int tok = tokens[dyn->pos[0] + m];
     const kg_u4* src = embed + (size_t)tok * d8;
     kg_u4* dst = out + (size_t)m * out_stride8;
     for (int i = threadIdx.x; i < d8; i += blockDim.x) dst[i] = src[i];
 }
 int kg_launch_embed(const KgDyn* dyn, const int* tokens, const void* embed, int d, void* out, int out_stride, hipStream_t st) {
     if (d % 8 || out_stride % 8) return -1;
-    hipLaunchKernelGGL(kg_embed_kernel, dim3(KG_MAX_ROWS), dim3(256), 0, st, dyn, tokens, (const kg_u4*)embed, d / 8, (kg_u4*)out, out_stride / 8);
+    hipLaunchKernelGGL(kg_embed_kernel, dim3(KG_GEMM_ROWS), dim3(256), 0, st, dyn, tokens, (const kg_u4*)embed, d / 8, (kg_u4*)out, out_stride / 8);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

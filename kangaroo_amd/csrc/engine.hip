@@ -23,6 +23,7 @@ static int g_ncu = 256;
 static void kg_init_once() {
     if (g_init) return;
     kg_linear_init();
+    kg_gemm_init();
     kg_attn_init();
     int dev = 0;
     hipDeviceProp_t p;
@@ -60,6 +61,8 @@ struct kg_session {
     KgPhase* prog_dev[3]; int prog_n[3]; size_t prog_smem[3]; int prog_cap;     // [2]: ad-hoc passes of kg_forward_layers
     unsigned* bar;                     // [0..255] barrier counters, [256] abort flag
     char* rot; size_t rot_layer;       // per-layer activation buffers of the persistent passes
+    char *pf_h, *pf_xq, *pf_ao, *pf_act;   // activations of a prefill pass (KG_GEMM_ROWS rows)
+    int gemm_prefill;                  // 1: prompts go through the 64-row GEMM passes
     unsigned long long* tlog;          // phase timeline of the last persistent launch (KG_PERSIST_TLOG=1), else null
     std::vector<int> prog_kinds[3];
     // graphs
@@ -101,9 +104,9 @@ static void carve(kg_session* s, Carver& c, const kg_shape* sh, int t_max) {
     char* adapter_h = c.take<char>(R * d * e);
     char* hs_early = c.take<char>((size_t)t_max * d * e);
     const int nsplit_max = 32;
-    float* part_o = c.take<float>((size_t)nsplit_max * R * qd);
-    float* part_ml = c.take<float>((size_t)nsplit_max * R * sh->num_heads * 2);
-    unsigned* attn_counters = c.take<unsigned>(2 * (size_t)sh->num_heads);
+    float* part_o = c.take<float>((size_t)nsplit_max * KG_GEMM_ROWS * qd);
+    float* part_ml = c.take<float>((size_t)nsplit_max * KG_GEMM_ROWS * sh->num_heads * 2);
+    unsigned* attn_counters = c.take<unsigned>(4 * (size_t)sh->num_heads);
     const int hp_stride = (sh->vocab_size + 15) / 16;
     float* head_part = c.take<float>((size_t)R * hp_stride * 4);
     int* head_tok = c.take<int>(R);
@@ -116,8 +119,14 @@ static void carve(kg_session* s, Carver& c, const kg_shape* sh, int t_max) {
     // per-layer activation buffers of the persistent passes: h after attention, h after the MLP, q, attention output, MLP activations
     const size_t rot_layer = R * (2 * d + 2 * qd + F) * e;
     char* rot = c.take<char>(rot_layer * sh->num_layers);
+    const size_t PR = KG_GEMM_ROWS;
+    char* pf_h = c.take<char>(PR * d * e);
+    char* pf_xq = c.take<char>(PR * qd * e);
+    char* pf_ao = c.take<char>(PR * qd * e);
+    char* pf_act = c.take<char>(PR * F * e);
     if (s) {
         s->prog_dev[0] = prog0; s->prog_dev[1] = prog1; s->prog_dev[2] = prog2; s->prog_cap = prog_cap; s->bar = bar; s->rot = rot; s->rot_layer = rot_layer;
+        s->pf_h = pf_h; s->pf_xq = pf_xq; s->pf_ao = pf_ao; s->pf_act = pf_act;
         s->state = state; s->tokens = tokens;
         s->dyn_shallow = dyn; s->dyn_adapter = dyn + 1; s->dyn_verify = dyn + 2; s->dyn_call = dyn + 3;
         s->h = h; s->h2 = h2; s->xq = xq; s->attn_out = attn_out; s->act = act; s->exited = exited;
@@ -154,12 +163,13 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     Carver c{(char*)buffers->workspace, 0};
     carve(s, c, shape, buffers->t_max);
     s->prefill_rows = prefill_rows_for(shape);
-    if (hipMemset(s->attn_counters, 0, 2 * (size_t)shape->num_heads * sizeof(unsigned)) != hipSuccess) { delete s; return fail(-2, "hipMemset failed"); }
+    if (hipMemset(s->attn_counters, 0, 4 * (size_t)shape->num_heads * sizeof(unsigned)) != hipSuccess) { delete s; return fail(-2, "hipMemset failed"); }
     for (int op = 0; op < 5; ++op) { s->waves[0][op] = 8; s->bpc[0][op] = 2; s->waves[1][op] = 8; s->bpc[1][op] = 1; }
     s->waves[0][1] = 4; s->waves[0][3] = 4;      // o_proj, down_proj: one row group per block, 4 waves measured best
     s->waves[1][3] = 2;                          // down_proj in the large-K MFMA mode
     s->v_transposed = (shape->head_dim >= 32 && buffers->t_max % 32 == 0) ? 1 : 0;
     s->attn_nsplit = 16;
+    s->gemm_prefill = s->v_transposed;           // the 64-row passes need the MFMA attention kernel
     s->attn_blocks = 16;                         // one chunk per block: long contexts need many CUs pulling K/V (one CU sustains only ~60 GB/s)
     s->round_graph = nullptr; s->round_graph_steps = -1; s->vanilla_graph = nullptr;
     s->prog_n[0] = s->prog_n[1] = s->prog_n[2] = 0;
@@ -201,6 +211,7 @@ extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
     if (value < 1) return fail(-1, "value must be >= 1");
     bool done = false;
     if (k == "attn_nsplit") { if (value > 32) return fail(-1, "nsplit <= 32"); s->attn_nsplit = value; done = true; }
+    if (k == "gemm_prefill") { s->gemm_prefill = (value >= 2 && s->v_transposed) ? 1 : 0; done = true; }   // 1: off, 2: on
     if (k == "attn_blocks") { if (value > 32) return fail(-1, "attn_blocks <= 32"); s->attn_blocks = value; done = true; }
     if (k == "persist") { s->persist = (value >= 2 && s->v_transposed && (g_ncu % 8) == 0) ? 1 : 0; done = true; }   // 1: off, 2: on
     for (int op = 0; op < 5 && !done; ++op)
@@ -235,6 +246,7 @@ extern "C" int kg_session_get(kg_session* s, const char* key) {
     }
     if (k == "attn_nsplit") return s->attn_nsplit;
     if (k == "attn_blocks") return s->attn_blocks;
+    if (k == "gemm_prefill") return s->gemm_prefill;
     if (k == "persist") return s->persist;
     if (k == "prefill_rows") return s->prefill_rows;
     return -1;
@@ -610,36 +622,81 @@ static int capture(kg_session* s, int mode, int steps, hipGraphExec_t* out) {
     return 0;
 }
 
-// Prefill: all layers over the prompt in chunks of prefill_rows rows; keeps the input of
-// the exit layer for the adapter's cache (inference_kangaroo.py:30-38).
+// One decoder layer on the <= KG_GEMM_ROWS rows described by dyn, through the prefill GEMM
+// kernels; in place on h.  lw.wgu == NULL: attention half only (the adapter layer).
+static int run_layer_gemm(kg_session* s, const kg_layer_weights& lw, void* kc, void* vc, const KgDyn* dyn,
+                          const void* h_in, void* h_out, hipStream_t st) {
+    const kg_shape& sh = s->sh;
+    const int d = sh.hidden_size, F = sh.intermediate_size, dt = sh.dtype;
+    {
+        KgLinArgs a = lin_base(dyn, lw.wqkv, s->q_dim + 2 * s->kv_dim, d, h_in, d);
+        a.norm_w = lw.norm1; a.eps = sh.rms_eps;
+        a.q_out = s->pf_xq; a.k_cache = kc; a.v_cache = vc;
+        a.rope_cos = s->w.rope_cos; a.rope_sin = s->w.rope_sin;
+        a.head_dim = sh.head_dim; a.q_dim = s->q_dim; a.kv_dim = s->kv_dim; a.t_max = s->buf.t_max; a.v_transposed = s->v_transposed;
+        KG_TRY(kg_launch_gemm(a, dt, PRO_RMSNORM, EPI_ROPE_KV, st));
+    }
+    {
+        KgAttnArgs a;
+        memset(&a, 0, sizeof(a));
+        a.dyn = dyn; a.q = s->pf_xq; a.k_cache = kc; a.v_cache = vc;
+        a.H = sh.num_heads; a.Hkv = sh.num_kv_heads; a.hd = sh.head_dim; a.t_max = s->buf.t_max; a.v_transposed = s->v_transposed;
+        a.nsplit = s->attn_nsplit; a.blocks_per_head = s->attn_blocks; a.part_o = s->part_o; a.part_ml = s->part_ml; a.counters = s->attn_counters;
+        a.out = s->pf_ao; a.max_rows = KG_GEMM_ROWS;
+        KG_TRY(kg_launch_attn(a, dt, st));
+    }
+    {
+        KgLinArgs a = lin_base(dyn, lw.wo, d, s->q_dim, s->pf_ao, s->q_dim);
+        a.out = h_out; a.out_stride = d; a.resid = h_in; a.resid_stride = d;
+        KG_TRY(kg_launch_gemm(a, dt, PRO_NONE, EPI_RESID, st));
+    }
+    if (lw.wgu == nullptr) return 0;
+    {
+        KgLinArgs a = lin_base(dyn, lw.wgu, 2 * F, d, h_out, d);
+        a.norm_w = lw.norm2; a.eps = sh.rms_eps;
+        a.out = s->pf_act; a.out_stride = F;
+        KG_TRY(kg_launch_gemm(a, dt, PRO_RMSNORM, EPI_SILU_MUL, st));
+    }
+    {
+        KgLinArgs a = lin_base(dyn, lw.wdown, d, F, s->pf_act, F);
+        a.out = h_out; a.out_stride = d; a.resid = h_out; a.resid_stride = d;
+        KG_TRY(kg_launch_gemm(a, dt, PRO_NONE, EPI_RESID, st));
+    }
+    return 0;
+}
+
+// Prefill: all layers over the prompt in passes of C rows (64-row GEMM passes, or prefill_rows
+// rows through the decode kernels); keeps the input of the exit layer for the adapter's cache
+// (inference_kangaroo.py:30-38).
 static int prefill(kg_session* s, int T0, bool with_adapter, hipStream_t st) {
     const kg_shape& sh = s->sh;
-    const int d = sh.hidden_size, L = sh.exit_layer, N = sh.num_layers, C = s->prefill_rows;
+    const int d = sh.hidden_size, L = sh.exit_layer, N = sh.num_layers;
+    const bool gemm = s->gemm_prefill && T0 > s->prefill_rows;
+    const int C = gemm ? KG_GEMM_ROWS : s->prefill_rows;
+    char* hb = gemm ? s->pf_h : s->h;
     const size_t rowb = (size_t)d * s->elt;
-    int last_n = 1;
     for (int c0 = 0; c0 < T0; c0 += C) {
         const int n = (T0 - c0 < C) ? (T0 - c0) : C;
-        last_n = n;
-        const int max_rows = C;
         KG_TRY(kg_launch_set_dyn(s->dyn_call, 1, n, c0, st));
-        KG_TRY(kg_launch_embed(s->dyn_call, s->tokens, s->w.embed, d, s->h, d, st));
-        const void* cur = s->h;
+        KG_TRY(kg_launch_embed(s->dyn_call, s->tokens, s->w.embed, d, hb, d, st));
+        const void* cur = hb;
         for (int l = 0; l < N; ++l) {
-            void* dst = (l == L - 1) ? (void*)(s->hs_early + (size_t)c0 * rowb) : (void*)s->h;
-            KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_call, max_rows, cur, dst, st));
+            void* dst = (l == L - 1) ? (void*)(s->hs_early + (size_t)c0 * rowb) : (void*)hb;
+            if (gemm) KG_TRY(run_layer_gemm(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_call, cur, dst, st));
+            else KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_call, C, cur, dst, st));
             cur = dst;
         }
     }
-    (void)last_n;
-    // first new token from the last row's logits (:33-34); dyn_call still describes the last chunk
+    // first new token from the last row's logits (:33-34); dyn_call still describes the last pass
     int nb = 0;
-    KG_TRY(run_head(s, s->dyn_call, 1, s->h, 1, s->w.final_norm, nullptr, &nb, st));
+    KG_TRY(run_head(s, s->dyn_call, 1, hb, 1, s->w.final_norm, nullptr, &nb, st));
     KG_TRY(kg_launch_vanilla_end(loop_bufs(s), s->head_part, nb, st));
     if (with_adapter) {
         for (int c0 = 0; c0 < T0; c0 += C) {
             const int n = (T0 - c0 < C) ? (T0 - c0) : C;
             KG_TRY(kg_launch_set_dyn(s->dyn_call, 1, n, c0, st));
-            KG_TRY(run_layer(s, s->w.adapter, s->buf.ak_cache, s->buf.av_cache, s->dyn_call, C, s->hs_early + (size_t)c0 * rowb, s->h2, st));
+            if (gemm) KG_TRY(run_layer_gemm(s, s->w.adapter, s->buf.ak_cache, s->buf.av_cache, s->dyn_call, s->hs_early + (size_t)c0 * rowb, s->pf_h, st));
+            else KG_TRY(run_layer(s, s->w.adapter, s->buf.ak_cache, s->buf.av_cache, s->dyn_call, C, s->hs_early + (size_t)c0 * rowb, s->h2, st));
         }
     }
     return 0;
@@ -844,7 +901,7 @@ extern "C" int kg_linear(int dtype, const void* w_packed, int N, int K, const vo
     g_err.clear();
     kg_init_once();
     if (!w_packed || !x || !out || !scratch) return fail(-1, "null argument");
-    if (n_rows < 1 || n_rows > KG_MAX_ROWS) return fail(-1, "n_rows must be in [1, 16]");
+    if (n_rows < 1 || n_rows > KG_GEMM_ROWS) return fail(-1, "n_rows must be in [1, 64]");
     if (epilogue != EPI_STORE && epilogue != EPI_RESID && epilogue != EPI_SILU_MUL) return fail(-1, "epilogue must be 0, 1 or 3");
     if (prologue == PRO_RMSNORM && !norm_w) return fail(-1, "norm_w required");
     if (epilogue == EPI_RESID && !resid) return fail(-1, "resid required");
@@ -853,7 +910,8 @@ extern "C" int kg_linear(int dtype, const void* w_packed, int N, int K, const vo
     KG_TRY(kg_launch_set_dyn(dyn, 1, n_rows, 0, st));
     KgLinArgs a = lin_base(dyn, w_packed, N, K, x, K);
     a.norm_w = norm_w; a.eps = eps; a.out = out; a.out_stride = out_stride; a.resid = resid; a.resid_stride = out_stride;
-    int rc = kg_launch_linear(a, dtype, n_rows, prologue, epilogue, nblocks > 0 ? nblocks : g_ncu * 2, nwaves > 0 ? nwaves : 8, st);
+    int rc = (n_rows > KG_MAX_ROWS) ? kg_launch_gemm(a, dtype, prologue, epilogue, st)       // prefill-sized pass
+                                    : kg_launch_linear(a, dtype, n_rows, prologue, epilogue, nblocks > 0 ? nblocks : g_ncu * 2, nwaves > 0 ? nwaves : 8, st);
     if (rc == -3) return fail(-3, "rows x K exceed LDS");
     if (rc) return fail(rc, "kg_launch_linear failed");
     return 0;
@@ -867,7 +925,7 @@ extern "C" int kg_qkv_rope_append(int dtype, const void* wqkv_packed, int d, int
     g_err.clear();
     kg_init_once();
     if (!wqkv_packed || !x || !norm_w || !rope_cos || !rope_sin || !q_out || !k_cache || !v_cache || !scratch) return fail(-1, "null argument");
-    if (n_rows < 1 || n_rows > KG_MAX_ROWS || pos0 < 0 || pos0 + n_rows > t_max) return fail(-1, "bad rows / positions");
+    if (n_rows < 1 || n_rows > KG_GEMM_ROWS || pos0 < 0 || pos0 + n_rows > t_max) return fail(-1, "bad rows / positions");
     hipStream_t st = (hipStream_t)stream;
     KgDyn* dyn = (KgDyn*)scratch;
     KG_TRY(kg_launch_set_dyn(dyn, 1, n_rows, pos0, st));
@@ -875,13 +933,14 @@ extern "C" int kg_qkv_rope_append(int dtype, const void* wqkv_packed, int d, int
     KgLinArgs a = lin_base(dyn, wqkv_packed, qd + 2 * kvd, d, x, d);
     a.norm_w = norm_w; a.eps = eps; a.q_out = q_out; a.k_cache = k_cache; a.v_cache = v_cache;
     a.rope_cos = rope_cos; a.rope_sin = rope_sin; a.head_dim = head_dim; a.q_dim = qd; a.kv_dim = kvd; a.t_max = t_max; a.v_transposed = v_transposed ? 1 : 0;
-    int rc = kg_launch_linear(a, dtype, n_rows, PRO_RMSNORM, EPI_ROPE_KV, nblocks > 0 ? nblocks : g_ncu * 2, nwaves > 0 ? nwaves : 8, st);
+    int rc = (n_rows > KG_MAX_ROWS) ? kg_launch_gemm(a, dtype, PRO_RMSNORM, EPI_ROPE_KV, st)
+                                    : kg_launch_linear(a, dtype, n_rows, PRO_RMSNORM, EPI_ROPE_KV, nblocks > 0 ? nblocks : g_ncu * 2, nwaves > 0 ? nwaves : 8, st);
     if (rc) return fail(rc, "kg_launch_linear failed");
     return 0;
 }
 
 extern "C" size_t kg_attention_scratch_bytes(int n_heads, int head_dim, int nsplit) {
-    return 256 + (size_t)nsplit * KG_MAX_ROWS * n_heads * (head_dim + 2) * sizeof(float) + 256 + 2 * (size_t)n_heads * sizeof(unsigned);
+    return 256 + (size_t)nsplit * KG_GEMM_ROWS * n_heads * (head_dim + 2) * sizeof(float) + 256 + 4 * (size_t)n_heads * sizeof(unsigned);
 }
 
 extern "C" int kg_attention(int dtype, const void* q, int n_rows, int pos0, const void* k_cache, const void* v_cache,
@@ -890,7 +949,7 @@ extern "C" int kg_attention(int dtype, const void* q, int n_rows, int pos0, cons
     g_err.clear();
     kg_init_once();
     if (!q || !k_cache || !v_cache || !out || !scratch) return fail(-1, "null argument");
-    if (n_rows < 1 || n_rows > KG_MAX_ROWS || pos0 < 0 || pos0 + n_rows > t_max || nsplit < 1 || nsplit > 32) return fail(-1, "bad argument");
+    if (n_rows < 1 || n_rows > (v_transposed ? KG_GEMM_ROWS : KG_MAX_ROWS) || pos0 < 0 || pos0 + n_rows > t_max || nsplit < 1 || nsplit > 32) return fail(-1, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     KgDyn* dyn = (KgDyn*)scratch;
     KG_TRY(kg_launch_set_dyn(dyn, 1, n_rows, pos0, st));
@@ -899,10 +958,10 @@ extern "C" int kg_attention(int dtype, const void* q, int n_rows, int pos0, cons
     a.dyn = dyn; a.q = q; a.k_cache = k_cache; a.v_cache = v_cache; a.H = n_heads; a.Hkv = n_kv_heads; a.hd = head_dim; a.t_max = t_max; a.v_transposed = v_transposed ? 1 : 0;
     a.nsplit = nsplit; a.blocks_per_head = nsplit; a.max_rows = n_rows;
     a.part_o = (float*)((char*)scratch + 256);
-    a.part_ml = a.part_o + (size_t)nsplit * KG_MAX_ROWS * n_heads * head_dim;
-    a.counters = (unsigned*)(((uintptr_t)(a.part_ml + (size_t)nsplit * KG_MAX_ROWS * n_heads * 2) + 255) & ~(uintptr_t)255);
-    KG_CHECK_HIP(hipMemsetAsync(a.counters, 0, 2 * (size_t)n_heads * sizeof(unsigned), st));
-    // partial buffers are indexed with max_rows = n_rows, within the KG_MAX_ROWS-sized scratch
+    a.part_ml = a.part_o + (size_t)nsplit * KG_GEMM_ROWS * n_heads * head_dim;
+    a.counters = (unsigned*)(((uintptr_t)(a.part_ml + (size_t)nsplit * KG_GEMM_ROWS * n_heads * 2) + 255) & ~(uintptr_t)255);
+    KG_CHECK_HIP(hipMemsetAsync(a.counters, 0, 4 * (size_t)n_heads * sizeof(unsigned), st));
+    // partial buffers are indexed with max_rows = n_rows, within the KG_GEMM_ROWS-sized scratch
     a.out = out;
     int rc = kg_launch_attn(a, dtype, st);
     if (rc) return fail(rc, "kg_launch_attn failed (head_dim 16/32/64/128; transposed V needs head_dim >= 32 and t_max % 32 == 0)");

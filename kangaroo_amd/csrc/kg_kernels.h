@@ -31,6 +31,9 @@ struct KgLinArgs {
 size_t kg_linear_smem(int mfma, int max_rows, int K, int nwaves);
 int kg_launch_linear(const KgLinArgs& a, int dtype, int max_rows, int pro, int epi, int nblocks, int nwaves, hipStream_t st);
 void kg_linear_init();
+// prefill passes: up to KG_GEMM_ROWS rows at consecutive positions dyn->pos[0] + m (see gemm.hip); EPI_HEAD is not offered
+int kg_launch_gemm(const KgLinArgs& a, int dtype, int pro, int epi, hipStream_t st);
+void kg_gemm_init();
 
 struct KgAttnArgs {
     const KgDyn* dyn;
@@ -43,9 +46,9 @@ struct KgAttnArgs {
     int blocks_per_head;        // MFMA kernel: blocks that share the chunks of one head (launch geometry only)
     float* part_o;              // [nsplit][rows][H][hd]
     float* part_ml;             // [nsplit][rows][H][2]
-    unsigned* counters;         // [2][H] arrival counters of the split merge; zero between launches
+    unsigned* counters;         // [4][H] arrival counters of the split merge; zero between launches
     void* out;                  // [n_rows, H*hd]
-    int max_rows;
+    int max_rows;               // upper bound of dyn->n_rows: <= 16, or <= KG_GEMM_ROWS for the MFMA kernel (16-row blocks on grid.z)
 };
 int kg_launch_attn(const KgAttnArgs& a, int dtype, hipStream_t st);
 void kg_attn_init();

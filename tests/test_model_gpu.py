@@ -248,3 +248,32 @@ def test_persistent_pass_is_bit_identical_to_kernel_by_kernel(shape_name, dtype)
         assert van_on == van_off
         assert van_on == on[0][0][:len(van_on)]
     eng.set_tuning(persist=2)
+
+
+@pytest.mark.parametrize("shape_name", ["small", "tinyllama-1.1b"])
+def test_gemm_prefill_matches_chunked_prefill(shape_name):
+    """Prompts longer than 16 tokens are prefilled in 64-row GEMM passes; switched off, in 16-row
+    passes of the decode kernels.  Same math, different K summation order: caches and the first
+    token's hidden state agree to 16-bit rounding noise."""
+    shape = get_shape(shape_name)
+    if shape_name == "tinyllama-1.1b":
+        shape = type(shape)(**{**shape.to_dict(), "num_hidden_layers": 4})
+    base, adapter = synth_state_dicts(shape, 2, seed=41, dtype=torch.float16, recipe=Recipe.agreeable(0.3, 8.0))
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, 2)
+    eng = model.engine
+    assert eng.get_tuning("gemm_prefill") == 1
+    g = torch.Generator().manual_seed(9)
+    for plen in (17, 64, 65, 200):
+        ids = torch.randint(3, shape.vocab_size, (1, plen), generator=g).cuda()
+        caches = {}
+        for mode in (2, 1):
+            eng.set_tuning(gemm_prefill=mode)
+            eng.k_cache.zero_(); eng.v_cache.zero_(); eng.ak_cache.zero_(); eng.av_cache.zero_()
+            out, st = eng.generate(ids[0], 1, mode="kangaroo")
+            torch.cuda.synchronize()
+            caches[mode] = (eng.k_cache.float().cpu().clone(), eng.v_cache.float().cpu().clone(),
+                            eng.ak_cache.float().cpu().clone(), eng.av_cache.float().cpu().clone(), out)
+        for a, b in zip(caches[2][:4], caches[1][:4]):
+            assert float(b.abs().max()) > 0
+            assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max())
+    eng.set_tuning(gemm_prefill=2)
