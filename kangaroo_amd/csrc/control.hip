@@ -41,23 +41,44 @@ __global__ void kg_rmsnorm_kernel(const KgDyn* dyn, const unsigned short* x, int
     if (m >= dyn->n_rows) return;
     __shared__ float red[4];
     const unsigned short* xr = x + (size_t)m * x_stride;
+    unsigned short* orow = out + (size_t)m * out_stride;
+    const bool vec = ((K | x_stride | out_stride) & 7) == 0;     // 16-byte pieces
     float ss = 0.f;
-    for (int i = threadIdx.x; i < K; i += blockDim.x) { float f = T::to_f(xr[i]); ss += f * f; }
+    if (vec) {
+        for (int i = threadIdx.x; i < (K >> 3); i += blockDim.x) {
+            const kg_us8 h = __builtin_bit_cast(kg_us8, ((const kg_u4*)xr)[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = T::to_f(h[e]); ss += f * f; }
+        }
+    } else {
+        for (int i = threadIdx.x; i < K; i += blockDim.x) { float f = T::to_f(xr[i]); ss += f * f; }
+    }
     ss = kg_wave_sum(ss);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
     ss = red[0] + red[1] + red[2] + red[3];
     const float rstd = rsqrtf(ss / (float)K + eps);
-    for (int i = threadIdx.x; i < K; i += blockDim.x) {
-        float f = kg_round<DT>(T::to_f(xr[i]) * rstd);
-        out[(size_t)m * out_stride + i] = T::from_f(T::to_f(w[i]) * f);
+    if (vec) {
+        for (int i = threadIdx.x; i < (K >> 3); i += blockDim.x) {
+            const kg_us8 h = __builtin_bit_cast(kg_us8, ((const kg_u4*)xr)[i]);
+            const kg_us8 g = __builtin_bit_cast(kg_us8, ((const kg_u4*)w)[i]);
+            kg_us8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = T::from_f(T::to_f(g[e]) * kg_round<DT>(T::to_f(h[e]) * rstd));
+            ((kg_u4*)orow)[i] = __builtin_bit_cast(kg_u4, o);
+        }
+    } else {
+        for (int i = threadIdx.x; i < K; i += blockDim.x) {
+            float f = kg_round<DT>(T::to_f(xr[i]) * rstd);
+            orow[i] = T::from_f(T::to_f(w[i]) * f);
+        }
     }
 }
 int kg_launch_rmsnorm(const KgDyn* dyn, const void* x, int x_stride, const void* w, float eps, int K, void* out, int out_stride, int dtype, hipStream_t st) {
     if (dtype == KG_F16)
-        hipLaunchKernelGGL(kg_rmsnorm_kernel<KG_F16>, dim3(KG_MAX_ROWS), dim3(256), 0, st, dyn, (const unsigned short*)x, x_stride, (const unsigned short*)w, eps, K, (unsigned short*)out, out_stride);
+        hipLaunchKernelGGL(kg_rmsnorm_kernel<KG_F16>, dim3(KG_GEMM_ROWS), dim3(256), 0, st, dyn, (const unsigned short*)x, x_stride, (const unsigned short*)w, eps, K, (unsigned short*)out, out_stride);
     else
-        hipLaunchKernelGGL(kg_rmsnorm_kernel<KG_BF16>, dim3(KG_MAX_ROWS), dim3(256), 0, st, dyn, (const unsigned short*)x, x_stride, (const unsigned short*)w, eps, K, (unsigned short*)out, out_stride);
+        hipLaunchKernelGGL(kg_rmsnorm_kernel<KG_BF16>, dim3(KG_GEMM_ROWS), dim3(256), 0, st, dyn, (const unsigned short*)x, x_stride, (const unsigned short*)w, eps, K, (unsigned short*)out, out_stride);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

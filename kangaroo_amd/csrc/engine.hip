@@ -61,7 +61,7 @@ struct kg_session {
     KgPhase* prog_dev[3]; int prog_n[3]; size_t prog_smem[3]; int prog_cap;     // [2]: ad-hoc passes of kg_forward_layers
     unsigned* bar;                     // [0..255] barrier counters, [256] abort flag
     char* rot; size_t rot_layer;       // per-layer activation buffers of the persistent passes
-    char *pf_h, *pf_xq, *pf_ao, *pf_act;   // activations of a prefill pass (KG_GEMM_ROWS rows)
+    char *pf_h, *pf_xn, *pf_xq, *pf_ao, *pf_act;   // activations of a prefill pass (KG_GEMM_ROWS rows)
     int gemm_prefill;                  // 1: prompts go through the 64-row GEMM passes
     unsigned long long* tlog;          // phase timeline of the last persistent launch (KG_PERSIST_TLOG=1), else null
     std::vector<int> prog_kinds[3];
@@ -121,12 +121,13 @@ static void carve(kg_session* s, Carver& c, const kg_shape* sh, int t_max) {
     char* rot = c.take<char>(rot_layer * sh->num_layers);
     const size_t PR = KG_GEMM_ROWS;
     char* pf_h = c.take<char>(PR * d * e);
+    char* pf_xn = c.take<char>(PR * d * e);
     char* pf_xq = c.take<char>(PR * qd * e);
     char* pf_ao = c.take<char>(PR * qd * e);
     char* pf_act = c.take<char>(PR * F * e);
     if (s) {
         s->prog_dev[0] = prog0; s->prog_dev[1] = prog1; s->prog_dev[2] = prog2; s->prog_cap = prog_cap; s->bar = bar; s->rot = rot; s->rot_layer = rot_layer;
-        s->pf_h = pf_h; s->pf_xq = pf_xq; s->pf_ao = pf_ao; s->pf_act = pf_act;
+        s->pf_h = pf_h; s->pf_xn = pf_xn; s->pf_xq = pf_xq; s->pf_ao = pf_ao; s->pf_act = pf_act;
         s->state = state; s->tokens = tokens;
         s->dyn_shallow = dyn; s->dyn_adapter = dyn + 1; s->dyn_verify = dyn + 2; s->dyn_call = dyn + 3;
         s->h = h; s->h2 = h2; s->xq = xq; s->attn_out = attn_out; s->act = act; s->exited = exited;
@@ -628,13 +629,15 @@ static int run_layer_gemm(kg_session* s, const kg_layer_weights& lw, void* kc, v
                           const void* h_in, void* h_out, hipStream_t st) {
     const kg_shape& sh = s->sh;
     const int d = sh.hidden_size, F = sh.intermediate_size, dt = sh.dtype;
+    // The norms run as kernels of their own here (64 rows are normalised once instead of once per
+    // block that stages them), in the reference's order: normalise, round, scale (adapter.py:254-259).
+    KG_TRY(kg_launch_rmsnorm(dyn, h_in, d, lw.norm1, sh.rms_eps, d, s->pf_xn, d, dt, st));
     {
-        KgLinArgs a = lin_base(dyn, lw.wqkv, s->q_dim + 2 * s->kv_dim, d, h_in, d);
-        a.norm_w = lw.norm1; a.eps = sh.rms_eps;
+        KgLinArgs a = lin_base(dyn, lw.wqkv, s->q_dim + 2 * s->kv_dim, d, s->pf_xn, d);
         a.q_out = s->pf_xq; a.k_cache = kc; a.v_cache = vc;
         a.rope_cos = s->w.rope_cos; a.rope_sin = s->w.rope_sin;
         a.head_dim = sh.head_dim; a.q_dim = s->q_dim; a.kv_dim = s->kv_dim; a.t_max = s->buf.t_max; a.v_transposed = s->v_transposed;
-        KG_TRY(kg_launch_gemm(a, dt, PRO_RMSNORM, EPI_ROPE_KV, st));
+        KG_TRY(kg_launch_gemm(a, dt, PRO_NONE, EPI_ROPE_KV, st));
     }
     {
         KgAttnArgs a;
@@ -651,11 +654,11 @@ static int run_layer_gemm(kg_session* s, const kg_layer_weights& lw, void* kc, v
         KG_TRY(kg_launch_gemm(a, dt, PRO_NONE, EPI_RESID, st));
     }
     if (lw.wgu == nullptr) return 0;
+    KG_TRY(kg_launch_rmsnorm(dyn, h_out, d, lw.norm2, sh.rms_eps, d, s->pf_xn, d, dt, st));
     {
-        KgLinArgs a = lin_base(dyn, lw.wgu, 2 * F, d, h_out, d);
-        a.norm_w = lw.norm2; a.eps = sh.rms_eps;
+        KgLinArgs a = lin_base(dyn, lw.wgu, 2 * F, d, s->pf_xn, d);
         a.out = s->pf_act; a.out_stride = F;
-        KG_TRY(kg_launch_gemm(a, dt, PRO_RMSNORM, EPI_SILU_MUL, st));
+        KG_TRY(kg_launch_gemm(a, dt, PRO_NONE, EPI_SILU_MUL, st));
     }
     {
         KgLinArgs a = lin_base(dyn, lw.wdown, d, F, s->pf_act, F);

@@ -13,12 +13,25 @@
 // accumulators go through the decode kernels' own epilogue code, so rounding is identical.
 #include "kg_linear_body.h"
 
-#define GEMM_NW 2                   // waves (= weight row groups) per block
-#define GEMM_XROW (8 * 64 + 16)     // bytes of one X row of a k-batch in LDS (+ pad)
-#define GEMM_STAGE (KG_GEMM_ROWS * 32 / (GEMM_NW * 64))     // 16-byte pieces of a batch each thread stages
+#ifndef GEMM_KB
+#define GEMM_KB 4                   // weight tiles (32 k each) per k-batch
+#endif
+#ifndef GEMM_RING
+#define GEMM_RING 8                 // weight batches per wave: GEMM_RING - 1 in flight
+#endif
+#define GEMM_XROW (GEMM_KB * 64)    // bytes of one X row of a k-batch in LDS: exactly one 256-byte bank row
+// 16-byte piece p of row `row` sits at piece slot p ^ (row & 15): the 16 lanes ds_read_b128 serves
+// together read 16 different rows at (nearly) one column, which the XOR spreads over all 16 slots.
+#define GEMM_XOFF(row, p) ((row) * GEMM_XROW + ((((p) ^ (row)) & 15) << 4))
+static_assert(GEMM_KB == 4, "the LDS swizzle assumes 256-byte rows");
 
-template <int DT, int PRO, int EPI>
+// GEMM_NW = waves (= weight row groups) per block: 4 shares one staged X batch among more
+// row groups; 2 keeps 128 blocks for the 4096-row projections.
+template <int DT, int PRO, int EPI, int GEMM_NW>
 __global__ void __launch_bounds__(GEMM_NW * 64) kg_gemm_kernel(const KgLinArgs a) {
+    constexpr int GEMM_STAGE = KG_GEMM_ROWS * (GEMM_KB * 4) / (GEMM_NW * 64);
+    constexpr int PPR = GEMM_KB * 4;                                   // 16-byte pieces per X row of a batch
+    constexpr int RPJ = GEMM_NW * 64 / PPR;                            // rows one staging step covers    // 16-byte pieces of a batch each thread stages
     typedef KgT<DT> T;
     const KgDyn* dyn = a.dyn;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -26,7 +39,7 @@ __global__ void __launch_bounds__(GEMM_NW * 64) kg_gemm_kernel(const KgLinArgs a
     const int pos0 = dyn->pos[0];
     const int M = dyn->n_rows;
     if (dyn->active == 0) return;
-    const int G = (a.N + 15) >> 4, KT = a.K >> 5, NB = (KT + 7) >> 3;
+    const int G = (a.N + 15) >> 4, KT = a.K >> 5, NB = (KT + GEMM_KB - 1) / GEMM_KB;
     const int rg = blockIdx.x * GEMM_NW + wave;        // >= G in the last block: loads out of range, nothing stored
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs0 = smem;
@@ -37,25 +50,31 @@ __global__ void __launch_bounds__(GEMM_NW * 64) kg_gemm_kernel(const KgLinArgs a
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(((size_t)(M - 1) * a.x_stride + a.K) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(PRO == PRO_RMSNORM ? a.norm_w : a.x), 0, a.K * 2, 0x00020000);
 
-    auto issue_w = [&](kg_u4 (&wv)[8], int b) {
+    // Blocks walk K in rotated order (block i starts at batch 5 i mod NB): otherwise every block
+    // asks for the same X columns at the same moment and those few L2 channels serialise the grid.
+    const int bstart = (int)((blockIdx.x * 5u) % (unsigned)NB);
+    auto kbatch = [&](int step) { int b = step + bstart; if (b >= NB) b -= NB; return (step < NB) ? b : NB; };   // NB: out of range
+    auto issue_w = [&](kg_u4 (&wv)[GEMM_KB], int step) {
+        const int b = kbatch(step);
         const unsigned base = (unsigned)rg * (unsigned)KT * 1024u + (unsigned)lane * 16u;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool ok = (rg < G) && (8 * b + u < KT);
-            wv[u] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, ok ? base + (unsigned)(8 * b + u) * 1024u : 0xFFFFFFFFu, 0, 2);
+        for (int u = 0; u < GEMM_KB; ++u) {
+            const bool ok = (rg < G) && (GEMM_KB * b + u < KT);
+            wv[u] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, ok ? base + (unsigned)(GEMM_KB * b + u) * 1024u : 0xFFFFFFFFu, 0, 2);
         }
     };
-    // staging: piece q = tid + 128 j covers row q >> 5, 16-byte column q & 31 of the batch
-    const int scol = tid & 31, srow0 = tid >> 5;
-    auto stage_load = [&](kg_u4 (&sx)[GEMM_STAGE], kg_u4& gw, int b) {
-        const bool kok = (8 * b + (scol >> 2)) < KT;
+    // staging: piece q = tid + nthreads * j covers row q / PPR, 16-byte column q % PPR of the batch
+    const int scol = tid % PPR, srow0 = tid / PPR;
+    auto stage_load = [&](kg_u4 (&sx)[GEMM_STAGE], kg_u4& gw, int step) {
+        const int b = kbatch(step);
+        const bool kok = (GEMM_KB * b + (scol >> 2)) < KT;
 #pragma unroll
         for (int j = 0; j < GEMM_STAGE; ++j) {
-            const int row = srow0 + (GEMM_NW * 2) * j;
+            const int row = srow0 + RPJ * j;
             const bool ok = kok && row < M;
-            sx[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(((size_t)row * a.x_stride + 256 * b + 8 * scol) * 2) : 0xFFFFFFFFu, 0, 0);
+            sx[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(((size_t)row * a.x_stride + 32 * GEMM_KB * b + 8 * scol) * 2) : 0xFFFFFFFFu, 0, 0);
         }
-        if (PRO == PRO_RMSNORM) gw = __builtin_amdgcn_raw_buffer_load_b128(nrsrc, kok ? (unsigned)((256 * b + 8 * scol) * 2) : 0xFFFFFFFFu, 0, 0);
+        if (PRO == PRO_RMSNORM) gw = __builtin_amdgcn_raw_buffer_load_b128(nrsrc, kok ? (unsigned)((32 * GEMM_KB * b + 8 * scol) * 2) : 0xFFFFFFFFu, 0, 0);
     };
     float ss[GEMM_STAGE];
 #pragma unroll
@@ -64,7 +83,7 @@ __global__ void __launch_bounds__(GEMM_NW * 64) kg_gemm_kernel(const KgLinArgs a
         const kg_us8 gg = __builtin_bit_cast(kg_us8, gw);
 #pragma unroll
         for (int j = 0; j < GEMM_STAGE; ++j) {
-            const int row = srow0 + (GEMM_NW * 2) * j;
+            const int row = srow0 + RPJ * j;
             kg_u4 v = sx[j];
             if (PRO == PRO_RMSNORM) {
                 kg_us8 h = __builtin_bit_cast(kg_us8, v);
@@ -77,44 +96,57 @@ __global__ void __launch_bounds__(GEMM_NW * 64) kg_gemm_kernel(const KgLinArgs a
                 }
                 v = __builtin_bit_cast(kg_u4, o);
             }
-            *(kg_u4*)(xs + row * GEMM_XROW + scol * 16) = v;
+            *(kg_u4*)(xs + GEMM_XOFF(row, scol)) = v;
         }
     };
 
     kg_f4 acc[KG_GEMM_ROWS / 16];
 #pragma unroll
     for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) acc[cb] = kg_f4{0.f, 0.f, 0.f, 0.f};
-    const int ncb = (M + 15) >> 4;                       // column blocks in use (uniform)
-    auto compute = [&](const kg_u4 (&wv)[8], const char* xs) {
+    // All four column blocks always run (rows past M are zeros in LDS): a branch per block would
+    // put every LDS read right in front of its MFMA with a full wait in between.
+    auto compute = [&](const kg_u4 (&wv)[GEMM_KB], const char* xs) {
+        kg_u4 x[GEMM_KB][KG_GEMM_ROWS / 16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < GEMM_KB; ++u)
 #pragma unroll
-            for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) {
-                if (cb < ncb) {
-                    const kg_u4 x = *(const kg_u4*)(xs + (16 * cb + r) * GEMM_XROW + u * 64 + g * 16);
-                    acc[cb] = T::mfma(wv[u], x, acc[cb]);
-                }
-            }
-        }
+            for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) x[u][cb] = *(const kg_u4*)(xs + GEMM_XOFF(16 * cb + r, 4 * u + g));
+#pragma unroll
+        for (int u = 0; u < GEMM_KB; ++u)
+#pragma unroll
+            for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) acc[cb] = T::mfma(wv[u], x[u][cb], acc[cb]);
     };
 
-    kg_u4 wA[8], wB[8], sx[GEMM_STAGE], gw = {0u, 0u, 0u, 0u};
-    stage_load(sx, gw, 0);
-    issue_w(wA, 0);
-    stage_store(sx, gw, xs0);
+    // Software pipeline.  Weights: ring of GEMM_RING register batches, all but one in flight (a
+    // CU runs one or two blocks here, so the bytes in flight per wave have to cover the HBM
+    // latency on their own).  X: batch b sits in LDS buffer b & 1; batches b+1 and b+2 are on
+    // their way in two register sets, and a set is stored to LDS one step after it was asked for.
+    constexpr int D = GEMM_RING;
+    static_assert(D % 2 == 0, "the ring is unrolled together with the two X register sets");
+    kg_u4 w[D][GEMM_KB];
+    kg_u4 sx0[GEMM_STAGE], sx1[GEMM_STAGE], gw0 = {0u, 0u, 0u, 0u}, gw1 = {0u, 0u, 0u, 0u};
+    stage_load(sx0, gw0, 0);
+    issue_w(w[0], 0);
+    stage_load(sx1, gw1, 1);
+#pragma unroll
+    for (int i = 1; i < D - 1; ++i) issue_w(w[i], i);
+    stage_store(sx0, gw0, xs0);
+    stage_load(sx0, gw0, 2);
     __syncthreads();
-    // batch b: weights in (wc), X in xs[b & 1]; the next batch's weights and X pieces are
-    // requested first, its X is written to the other buffer after the MFMAs of this batch
-    auto step = [&](kg_u4 (&wc)[8], kg_u4 (&wn)[8], int b) {
-        stage_load(sx, gw, b + 1);
-        issue_w(wn, b + 1);
+    // step b: weights W(b) in wc; wr is the ring slot freed by step b-1; (sxe, gwe) holds X(b+1)
+    auto step = [&](kg_u4 (&wc)[GEMM_KB], kg_u4 (&wr)[GEMM_KB], kg_u4 (&sxe)[GEMM_STAGE], kg_u4& gwe, int b) {
+        issue_w(wr, b + D - 1);
         compute(wc, (b & 1) ? xs1 : xs0);
-        stage_store(sx, gw, (b & 1) ? xs0 : xs1);
+        stage_store(sxe, gwe, (b & 1) ? xs0 : xs1);
+        stage_load(sxe, gwe, b + 3);
         __syncthreads();
     };
-    for (int b = 0; b < NB; b += 2) {
-        step(wA, wB, b);
-        step(wB, wA, b + 1);         // past the last batch: zeros in, zeros added
+    for (int b = 0; b < NB; b += D) {      // batches past the last one: zeros in, zeros added
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            if (i & 1) step(w[i], w[(i + D - 1) % D], sx0, gw0, b + i);
+            else step(w[i], w[(i + D - 1) % D], sx1, gw1, b + i);
+        }
     }
 
     // ---- row factors of the deferred RMSNorm ----
@@ -123,8 +155,8 @@ __global__ void __launch_bounds__(GEMM_NW * 64) kg_gemm_kernel(const KgLinArgs a
         for (int j = 0; j < GEMM_STAGE; ++j) {
             float t = ss[j];
 #pragma unroll
-            for (int o = 1; o < 32; o <<= 1) t += __shfl_xor(t, o, 64);
-            if ((lane & 31) == 0) ssum[srow0 + (GEMM_NW * 2) * j] = t;
+            for (int o = 1; o < PPR; o <<= 1) t += __shfl_xor(t, o, 64);
+            if ((lane & (PPR - 1)) == 0) ssum[srow0 + RPJ * j] = t;
         }
     }
     // ---- epilogue inputs through LDS (the X buffers are free now), laid out as the decode epilogues expect ----
@@ -158,44 +190,53 @@ __global__ void __launch_bounds__(GEMM_NW * 64) kg_gemm_kernel(const KgLinArgs a
     }
 }
 
+static int g_gemm_ncu = 256;
 static size_t gemm_smem() { return (size_t)2 * KG_GEMM_ROWS * GEMM_XROW + KG_GEMM_ROWS * sizeof(float); }
 
-template <int DT, int PRO>
-static int launch_epi(const KgLinArgs& a, int epi, dim3 grid, hipStream_t st) {
-    const dim3 block(GEMM_NW * 64);
+template <int DT, int PRO, int NW>
+static int launch_epi(const KgLinArgs& a, int epi, hipStream_t st) {
+    const int G = (a.N + 15) / 16;
+    const dim3 grid((G + NW - 1) / NW), block(NW * 64);
     const size_t smem = gemm_smem();
     switch (epi) {
-    case EPI_STORE: hipLaunchKernelGGL((kg_gemm_kernel<DT, PRO, EPI_STORE>), grid, block, smem, st, a); break;
-    case EPI_RESID: hipLaunchKernelGGL((kg_gemm_kernel<DT, PRO, EPI_RESID>), grid, block, smem, st, a); break;
-    case EPI_ROPE_KV: hipLaunchKernelGGL((kg_gemm_kernel<DT, PRO, EPI_ROPE_KV>), grid, block, smem, st, a); break;
-    case EPI_SILU_MUL: hipLaunchKernelGGL((kg_gemm_kernel<DT, PRO, EPI_SILU_MUL>), grid, block, smem, st, a); break;
+    case EPI_STORE: hipLaunchKernelGGL((kg_gemm_kernel<DT, PRO, EPI_STORE, NW>), grid, block, smem, st, a); break;
+    case EPI_RESID: hipLaunchKernelGGL((kg_gemm_kernel<DT, PRO, EPI_RESID, NW>), grid, block, smem, st, a); break;
+    case EPI_ROPE_KV: hipLaunchKernelGGL((kg_gemm_kernel<DT, PRO, EPI_ROPE_KV, NW>), grid, block, smem, st, a); break;
+    case EPI_SILU_MUL: hipLaunchKernelGGL((kg_gemm_kernel<DT, PRO, EPI_SILU_MUL, NW>), grid, block, smem, st, a); break;
     default: return -1;
     }
     return 0;
+}
+template <int DT, int PRO>
+static int launch_nw(const KgLinArgs& a, int epi, hipStream_t st) {
+    const int G = (a.N + 15) / 16;
+    return (G >= 4 * g_gemm_ncu / 2) ? launch_epi<DT, PRO, 4>(a, epi, st) : launch_epi<DT, PRO, 2>(a, epi, st);
 }
 
 // Rows and positions come from a.dyn: n_rows <= KG_GEMM_ROWS rows at positions pos[0], pos[0]+1, ...
 int kg_launch_gemm(const KgLinArgs& a, int dtype, int pro, int epi, hipStream_t st) {
     if (a.K % 32 != 0 || a.K <= 0 || a.N <= 0) return -1;
-    if (epi == EPI_ROPE_KV && (size_t)KG_GEMM_ROWS * a.head_dim * 4 > (size_t)KG_GEMM_ROWS * GEMM_XROW) return -1;
-    const int G = (a.N + 15) / 16;
-    const dim3 grid((G + GEMM_NW - 1) / GEMM_NW);
+    if (epi == EPI_ROPE_KV && (size_t)KG_GEMM_ROWS * a.head_dim * 4 > (size_t)2 * KG_GEMM_ROWS * GEMM_XROW) return -1;     // cos/sin rows reuse both X buffers
     int rc;
-    if (dtype == KG_F16) rc = (pro == PRO_NONE) ? launch_epi<KG_F16, PRO_NONE>(a, epi, grid, st) : launch_epi<KG_F16, PRO_RMSNORM>(a, epi, grid, st);
-    else rc = (pro == PRO_NONE) ? launch_epi<KG_BF16, PRO_NONE>(a, epi, grid, st) : launch_epi<KG_BF16, PRO_RMSNORM>(a, epi, grid, st);
+    if (dtype == KG_F16) rc = (pro == PRO_NONE) ? launch_nw<KG_F16, PRO_NONE>(a, epi, st) : launch_nw<KG_F16, PRO_RMSNORM>(a, epi, st);
+    else rc = (pro == PRO_NONE) ? launch_nw<KG_BF16, PRO_NONE>(a, epi, st) : launch_nw<KG_BF16, PRO_RMSNORM>(a, epi, st);
     if (rc) return rc;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-template <int DT, int PRO> static void set_attr_all() {
+template <int DT, int PRO, int NW> static void set_attr_all() {
     const int lim = (int)gemm_smem();
-    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, PRO, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, PRO, EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, PRO, EPI_ROPE_KV>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, PRO, EPI_SILU_MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, PRO, EPI_STORE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, PRO, EPI_RESID, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, PRO, EPI_ROPE_KV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, PRO, EPI_SILU_MUL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
 }
 void kg_gemm_init() {
-    set_attr_all<KG_F16, PRO_NONE>(); set_attr_all<KG_F16, PRO_RMSNORM>();
-    set_attr_all<KG_BF16, PRO_NONE>(); set_attr_all<KG_BF16, PRO_RMSNORM>();
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) g_gemm_ncu = ncu;
+    set_attr_all<KG_F16, PRO_NONE, 2>(); set_attr_all<KG_F16, PRO_RMSNORM, 2>();
+    set_attr_all<KG_BF16, PRO_NONE, 2>(); set_attr_all<KG_BF16, PRO_RMSNORM, 2>();
+    set_attr_all<KG_F16, PRO_NONE, 4>(); set_attr_all<KG_F16, PRO_RMSNORM, 4>();
+    set_attr_all<KG_BF16, PRO_NONE, 4>(); set_attr_all<KG_BF16, PRO_RMSNORM, 4>();
     (void)hipGetLastError();
 }
