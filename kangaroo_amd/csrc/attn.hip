@@ -184,7 +184,11 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_kernel(const KgAttnArgs a
             }
         }
     }
-    if (n_act > 1 && split_arrive(a.counters + blockIdx.z * a.H + h, n_act)) split_combine<DT, false>(a, h, hd, m0, mr, n_act, threadIdx.x, blockDim.x);
+    if (n_act > 1) {
+        __shared__ KgAttnCombineLds cl;
+        const bool last = split_arrive(a.counters + blockIdx.z * a.H + h, n_act);
+        split_combine<DT, false>(a, h, hd, m0, mr, n_act, threadIdx.x, blockDim.x, cl, last);
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -319,7 +323,8 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnA
         }
         return;
     }
-    if (split_arrive(a.counters + blockIdx.z * a.H + h, nblk_act)) split_combine<DT, false>(a, h, HD, row0, M, n_act, tid, ATT_NW * 64);
+    const bool last = split_arrive(a.counters + blockIdx.z * a.H + h, nblk_act);
+    split_combine<DT, false>(a, h, HD, row0, M, n_act, tid, ATT_NW * 64, lds.cl, last);
 }
 
 template <int DT, int LPR>
@@ -371,7 +376,7 @@ void kg_attn_init() {
 }
 
 int kg_launch_attn(const KgAttnArgs& a, int dtype, hipStream_t st) {
-    if (!a.counters || a.nsplit < 1 || a.max_rows < 1 || a.max_rows > (a.v_transposed ? KG_GEMM_ROWS : KG_MAX_ROWS) || a.H % a.Hkv != 0) return -1;
+    if (!a.counters || a.nsplit < 1 || a.nsplit > KG_ATTN_MAX_SPLITS || a.max_rows < 1 || a.max_rows > (a.v_transposed ? KG_GEMM_ROWS : KG_MAX_ROWS) || a.H % a.Hkv != 0) return -1;
     if (a.v_transposed && (a.t_max % 32 != 0)) return -1;
     int rc = (dtype == KG_F16) ? launch_dt<KG_F16>(a, st) : launch_dt<KG_BF16>(a, st);
     if (rc) return rc;

@@ -20,27 +20,90 @@
 __device__ __forceinline__ void coh_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, KG_AGENT); }
 __device__ __forceinline__ float coh_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, KG_AGENT); }
 
-// out[m][h][:] = sum_s w_s o_s / sum_s w_s l_s,  w_s = exp(m_s - max_s m_s), rows m0 .. m0+mr-1;
-// run by the `nthr` threads tid = 0..nthr-1 of one team
+#define KG_ATTN_MAX_SPLITS 32
+
+// LDS scratch of split_combine (one per team that may run it)
+struct KgAttnCombineLds {
+    float f[KG_ATTN_MAX_SPLITS][KG_MAX_ROWS];      // weight of split s for row m: exp(m_s - max_s m_s)
+    float l[KG_MAX_ROWS];                          // sum_s f_s l_s
+};
+
+// out[m][h][:] = sum_s f_s o_s / sum_s f_s l_s,  f_s = exp(m_s - max_s m_s), rows m0 .. m0+mr-1 (mr <= 16);
+// run by the `nthr` threads tid = 0..nthr-1 of one team, which share `cl`.  EVERY thread of the block
+// must make the call (it contains a block barrier); teams with active == false only keep it company.
+// The partials come from memory with device-coherent loads, each a round trip of a microsecond
+// or more, so they are requested in bulk: first every (max, sum) pair, then for each output
+// element its ns partial sums, 8 splits at a time, before anything waits.  The sums run in split
+// order.
 template <int DT, bool COH>
-__device__ __forceinline__ void split_combine(const KgAttnArgs& a, int h, int hd, int m0, int mr, int ns, int tid, int nthr) {
+__device__ __forceinline__ void split_combine(const KgAttnArgs& a, int h, int hd, int m0, int mr, int ns, int tid, int nthr,
+                                              KgAttnCombineLds& cl, bool active) {
     typedef KgT<DT> T;
-    for (int i = tid; i < mr * hd; i += nthr) {
-        const int m = m0 + i / hd, dmi = i % hd;
-        float mx = -INFINITY;
-        for (int s = 0; s < ns; ++s) mx = fmaxf(mx, coh_load(a.part_ml + (((size_t)s * a.max_rows + m) * a.H + h) * 2));
-        float o = 0.f, l = 0.f;
-        for (int s = 0; s < ns; ++s) {
-            const float* ml = a.part_ml + (((size_t)s * a.max_rows + m) * a.H + h) * 2;
-            const float m_s = coh_load(ml);
-            const float f = (m_s == -INFINITY) ? 0.f : expf(m_s - mx);
-            o += f * coh_load(a.part_o + (((size_t)s * a.max_rows + m) * a.H + h) * hd + dmi);
-            l += f * coh_load(ml + 1);
+    // the first 16 splits' partial sums of this thread's (up to four) output elements: requested
+    // before anything else, so that they travel together with phase A's (max, sum) pairs
+    const int total = active ? mr * hd : 0;
+    float v[4][16];
+    auto load_v = [&](int i0, int s0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * nthr + tid;
+            const int ml = (i < total) ? i / hd : 0, dmi = (i < total) ? i % hd : 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int s = (s0 + j < ns) ? s0 + j : 0;
+                v[k][j] = coh_load(a.part_o + (((size_t)s * a.max_rows + m0 + ml) * a.H + h) * hd + dmi);
+            }
         }
-        unsigned short* dst = (unsigned short*)a.out + (size_t)m * a.H * hd + (size_t)h * hd + dmi;
-        const unsigned short v = T::from_f(o / l);
-        if (COH) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, KG_AGENT);
-        else *dst = v;
+    };
+    if (total > 0) load_v(0, 0);
+    // phase A: one thread per row
+    if (active && tid < mr) {
+        const int m = m0 + tid;
+        float ms[KG_ATTN_MAX_SPLITS], ls[KG_ATTN_MAX_SPLITS];
+#pragma unroll
+        for (int s = 0; s < KG_ATTN_MAX_SPLITS; ++s) {
+            const float* ml = a.part_ml + (((size_t)(s < ns ? s : 0) * a.max_rows + m) * a.H + h) * 2;
+            ms[s] = coh_load(ml); ls[s] = coh_load(ml + 1);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < KG_ATTN_MAX_SPLITS; ++s) if (s < ns) mx = fmaxf(mx, ms[s]);
+        float l = 0.f;
+#pragma unroll
+        for (int s = 0; s < KG_ATTN_MAX_SPLITS; ++s) {
+            if (s < ns) {
+                const float f = (ms[s] == -INFINITY) ? 0.f : expf(ms[s] - mx);
+                cl.f[s][tid] = f;
+                l += f * ls[s];
+            }
+        }
+        cl.l[tid] = l;
+    }
+    __syncthreads();
+    // phase B: output elements i = tid + nthr * k
+    for (int i0 = 0; i0 < total; i0 += 4 * nthr) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < ns; s0 += 16) {
+            if (i0 > 0 || s0 > 0) load_v(i0, s0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * nthr + tid;
+                const int ml = (i < total) ? i / hd : 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) if (s0 + j < ns) o[k] += cl.f[s0 + j][ml] * v[k][j];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * nthr + tid;
+            if (i < total) {
+                const int ml = i / hd, dmi = i % hd;
+                unsigned short* dst = (unsigned short*)a.out + (size_t)(m0 + ml) * a.H * hd + (size_t)h * hd + dmi;
+                const unsigned short r = T::from_f(o[k] / cl.l[ml]);
+                if (COH) __hip_atomic_store(dst, r, __ATOMIC_RELAXED, KG_AGENT);
+                else *dst = r;
+            }
+        }
     }
 }
 
@@ -48,6 +111,7 @@ __device__ __forceinline__ void split_combine(const KgAttnArgs& a, int h, int hd
 template <int HD> struct KgAttnTeamLds {
     float o[ATT_NW][KG_MAX_ROWS][HD];
     float ml[ATT_NW][KG_MAX_ROWS][2];
+    KgAttnCombineLds cl;
     int last;
 };
 
@@ -226,7 +290,7 @@ __device__ __forceinline__ void kg_attn_mfma_item(const KgAttnArgs& a, bool vali
             lds.last = last;
         }
         __syncthreads();
-        if (lds.last) split_combine<DT, COH>(a, h, HD, 0, M, n_act, ttid, ATT_NW * 64);
+        split_combine<DT, COH>(a, h, HD, 0, M, n_act, ttid, ATT_NW * 64, lds.cl, lds.last != 0);
     }
     __syncthreads();                                           // the team's LDS is free for the next item
 }
