@@ -20,6 +20,16 @@
 #include "kg_common.h"
 #include "kg_kernels.h"
 
+// Optional in-kernel timeline for the microbenchmarks (scripts/microbench.hip defines KG_LIN_TLOG and
+// the buffer): thread 0 of every block stamps the 100 MHz clock at a few points of the pass:
+// 0 entry, 1 parameters known, 2 X in LDS (after the block barrier), 3 first row group reduced, 4 end.
+#ifdef KG_LIN_TLOG
+extern __device__ unsigned long long kg_lin_tlog[];
+#define KG_TSTAMP(a, i) do { if (threadIdx.x == 0) kg_lin_tlog[((size_t)(a).logits_stride * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define KG_TSTAMP(a, i) do { } while (0)
+#endif
+
 #ifndef KG_U_VEC
 #define KG_U_VEC 8      // weight tiles (KiB) per batch and wave; two batches are in flight
 #endif
@@ -239,6 +249,7 @@ __device__ __forceinline__ void prologue_finish(const KgLinArgs& a, const ProReg
 template <int DT, int MODE, int PRO, int EPI, bool PERSIST>
 __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, KgGridBar* gb, int nwaves) {
     typedef KgT<DT> T;
+    KG_TSTAMP(a, 0);
     constexpr bool COH = PERSIST;                       // outputs: written through to memory
     constexpr bool COH_LD = PERSIST && KG_PERSIST_COH_LOADS; // inputs written by other blocks earlier in this kernel
     const KgDyn* dyn = a.dyn;
@@ -284,6 +295,7 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
     const int active = dyn->active;
     const int n_rows = dyn->n_rows;
     if (!PERSIST && active == 0) return;
+    KG_TSTAMP(a, 1);
     const int M = (MODE == MODE_VEC) ? 1 : n_rows;
     constexpr int RM = (MODE == MODE_VEC) ? 1 : KG_MAX_ROWS;
     constexpr int GX_ROW = 8 * 64 + 16;                           // bytes of one X row of a batch in a wave's LDS slot (+ pad)
@@ -425,6 +437,7 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
     }
     if (MODE != MODE_MFMA_GX && pro_fast) prologue_finish<DT, PRO, RM>(a, pr, xs, xs_stride, ss, M, tid);
     __syncthreads();
+    KG_TSTAMP(a, 2);
 
     HeadRun run; run.mx = -INFINITY; run.sum = 0.f; run.idx = 0;
     float rstd = 1.f;
@@ -489,6 +502,7 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
                 }
             }
             __syncthreads();
+            if (it == 0) KG_TSTAMP(a, 3);
             const int n_epi = (MODE == MODE_VEC) ? 8 : 128;
             if (tid < n_epi) {
                 const int m = tid >> 3, p = tid & 7;
@@ -536,5 +550,6 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
             }
         }
     }
+    KG_TSTAMP(a, 4);
     if (PERSIST) gb->arrive();
 }

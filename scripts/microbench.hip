@@ -1,7 +1,8 @@
 // Kernel microbenchmarks (GPU box): launch-boundary cost and linear-kernel bandwidth sweeps.
 // Build: make -C kangaroo_amd/csrc microbench     Run: kangaroo_amd/csrc/microbench [what]
-#include "../kangaroo_amd/csrc/kg_common.h"
-#include "../kangaroo_amd/csrc/kg_kernels.h"
+#define KG_LIN_TLOG
+#include "../kangaroo_amd/csrc/kg_linear_body.h"
+__device__ unsigned long long kg_lin_tlog[64 * 256 * 8];
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -77,6 +78,17 @@ template <int V> __global__ __launch_bounds__(512) void k_barrier_chain(unsigned
         v = __hip_atomic_load(data + (p & 1) * nb + blockIdx.x, __ATOMIC_RELAXED, AG);
     }
     if (threadIdx.x == 0) data[2 * nb + blockIdx.x] = v;
+}
+
+// timeline copy of the verify pass's gate/up kernel (stand-alone form of the body, with stamps)
+__global__ void __launch_bounds__(512) k_lin_tl(const KgLinArgs a_in) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    KgLinArgs a = a_in;
+    // where X comes from: 0 one copy for all blocks, 1 a copy per block, 2 a copy per blockIdx % 8
+    const size_t copy = (size_t)16 * a.K * 2;
+    if (a.head_part_stride == 1) a.x = (const char*)a.x + copy * blockIdx.x;
+    if (a.head_part_stride == 2) a.x = (const char*)a.x + copy * (blockIdx.x & 7);
+    kg_linear_body<KG_F16, MODE_MFMA, PRO_RMSNORM, EPI_STORE, false>(a, smem, nullptr, blockDim.x >> 6);
 }
 
 static float time_graph(hipStream_t st, hipGraphExec_t ge, int reps) {
@@ -196,6 +208,57 @@ int main(int argc, char** argv) {
                 CK(hipGraphExecDestroy(ge));
             }
         }
+    }
+    if (what == "timeline") {
+        // 32 back-to-back launches of a gate/up-sized MFMA pass (7 rows) in one graph; per block the
+        // stamps are: entry, parameters known, X in LDS, first row group reduced, end.
+        const int N = 22016, K = 4096, nlaunch = 32, nb = 256, nw_ = 8;
+        size_t bytes = (size_t)N * K * 2;
+        char* xcopies; CK(hipMalloc(&xcopies, (size_t)256 * 16 * K * 2)); CK(hipMemset(xcopies, 0, (size_t)256 * 16 * K * 2));
+        for (int xmode = 0; xmode < 3; ++xmode) {
+        (void)hipFuncSetAttribute((const void*)k_lin_tl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipGraphExec_t ge = capture(st, [&]() {
+            size_t off = 0;
+            for (int i = 0; i < nlaunch; ++i) {
+                if (off + bytes > pool_bytes) off = 0;
+                KgLinArgs a; memset(&a, 0, sizeof(a));
+                a.W = pool + off; a.N = N; a.K = K; a.dyn = dyn + 1; a.x = xcopies; a.x_stride = K; a.head_part_stride = xmode;
+                a.out = out; a.out_stride = N; a.norm_w = nw; a.eps = 1e-6f;
+                a.side_bytes = 512; a.logits_stride = i;
+                const size_t smem = 512 + (size_t)2 * nw_ * 256 * 4 + (size_t)7 * (K * 2 + 32);
+                hipLaunchKernelGGL(k_lin_tl, dim3(nb), dim3(nw_ * 64), smem, st, a);
+                off += bytes;
+            }
+        });
+        float ms = time_graph(st, ge, 2) / nlaunch;
+        printf("X source %d: timeline kernel %.1f us per launch\n", xmode, ms * 1e3);
+        std::vector<unsigned long long> t((size_t)nlaunch * nb * 8);
+        CK(hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(kg_lin_tlog), t.size() * 8));
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        int cnt = 0;
+        for (int i = 1; i < nlaunch; ++i) {
+            unsigned long long prev_end = 0, first_entry = ~0ull, last_entry = 0, first_end = ~0ull, last_end = 0;
+            for (int b = 0; b < nb; ++b) { unsigned long long e = t[((size_t)(i - 1) * nb + b) * 8 + 4]; if (e > prev_end) prev_end = e; }
+            double d1 = 0, d2 = 0, d3 = 0;
+            for (int b = 0; b < nb; ++b) {
+                const unsigned long long* s = &t[((size_t)i * nb + b) * 8];
+                if (s[0] < first_entry) first_entry = s[0];
+                if (s[0] > last_entry) last_entry = s[0];
+                if (s[4] < first_end) first_end = s[4];
+                if (s[4] > last_end) last_end = s[4];
+                d1 += (double)(s[1] - s[0]); d2 += (double)(s[2] - s[1]); d3 += (double)(s[3] - s[2]); 
+            }
+            acc[0] += (double)((long long)(first_entry - prev_end)) * 0.01;    // previous kernel's last block end -> this kernel's first block entry
+            acc[1] += (double)(last_entry - first_entry) * 0.01;               // entry skew over blocks
+            acc[2] += d1 / nb * 0.01; acc[3] += d2 / nb * 0.01; acc[4] += d3 / nb * 0.01;
+            acc[5] += (double)(last_end - first_end) * 0.01;                   // end skew over blocks
+            ++cnt;
+        }
+        printf("gap prev-end -> first entry %.2f us | entry skew %.2f | entry->params %.2f | params->X in LDS %.2f | X->first row group %.2f | end skew %.2f\n",
+               acc[0] / cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[5] / cnt);
+        CK(hipGraphExecDestroy(ge));
+        }
+        return 0;
     }
     if (what == "all" || what == "linear") {
         Shape shapes[] = {{"qkv", 12288, 4096}, {"o", 4096, 4096}, {"gateup", 22016, 4096}, {"down", 4096, 11008}, {"head", 32000, 4096}};
