@@ -88,7 +88,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # rehearsal knobs for a box with fewer GPUs than ranks: KG_BENCH_BACKEND=gloo KG_BENCH_DEVICE=0
+        backend = os.environ.get("KG_BENCH_BACKEND", "nccl")
+        if "KG_BENCH_DEVICE" in os.environ:
+            local_rank = int(os.environ["KG_BENCH_DEVICE"])
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -126,7 +133,7 @@ def main():
     barrier()
     elapsed = time.time() - t0
     new_tokens = sum(s.new_tokens for s in stats)
-    tot = torch.tensor([float(new_tokens), elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(new_tokens), elapsed], dtype=torch.float64, device=dev if dist is None or dist.get_backend() == "nccl" else "cpu")
     if dist is not None:
         tmax = tot.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
