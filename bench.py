@@ -3,8 +3,8 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one whole kangaroo_forward call (prefill + draft/verify rounds) on one
-synthetic Spec-Bench-shaped prompt.  At N=1 the workload is BASELINE.json's
-configs[1]: Vicuna-7B shape, fp16, exitlayer=2, steps=6, threshold=0.6, greedy,
+synthetic Spec-Bench-shaped prompt.  At N=1 the workload is the reference's
+headline configuration: Vicuna-7B shape, fp16, exitlayer=2, steps=6, threshold=0.6, greedy,
 max_new_tokens=1024, random-init weights with a recipe calibrated so the mean accept
 length is near the reference's recorded 2.05.  For N>1 (launched by
 torch.distributed.run, one rank per GPU) every rank holds a full replica and decodes
