@@ -277,3 +277,31 @@ def test_gemm_prefill_matches_chunked_prefill(shape_name):
             assert float(b.abs().max()) > 0
             assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max())
     eng.set_tuning(gemm_prefill=2)
+
+
+def test_full_size_7b_losslessness_and_determinism():
+    """At the benchmark's size (Vicuna-7B shape, exit layer 2, 6 draft steps, threshold 0.6) no CPU
+    oracle finishes in seconds; the size-independent properties are checked instead: Kangaroo's
+    output equals plain greedy decoding on the same kernels token for token, accept lengths add up
+    to the new tokens, every round accepts between 1 and steps+1 tokens and never more than it
+    drafted + 1, and a second run reproduces the first bit for bit."""
+    shape = get_shape("vicuna-7b")
+    base, adapter = synth_state_dicts(shape, 2, seed=0, dtype=torch.float16, recipe=Recipe.agreeable(0.08, 10.0), device="cuda")
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, 2, release_source=True)
+    del base, adapter
+    eng = model.engine
+    g = torch.Generator().manual_seed(77)
+    for plen, new in ((23, 160), (300, 96)):
+        ids = torch.randint(3, shape.vocab_size, (plen,), generator=g)
+        out, st = eng.generate(ids, new, mode="kangaroo")
+        out2, st2 = eng.generate(ids, new, mode="kangaroo")
+        van, _ = eng.generate(ids, st.new_tokens, mode="vanilla")
+        assert out == out2 and st.accept_lengths == st2.accept_lengths and st.draft_lengths == st2.draft_lengths
+        assert out == van
+        assert out[:plen] == ids.tolist()
+        assert 1 + sum(st.accept_lengths) == st.new_tokens
+        assert len(st.accept_lengths) == len(st.draft_lengths) == st.rounds
+        assert all(1 <= a <= 7 and a <= d + 1 and 1 <= d <= 6 for a, d in zip(st.accept_lengths, st.draft_lengths))
+        assert new - 1 - 6 <= st.new_tokens <= new
+    del model, eng
+    torch.cuda.empty_cache()
