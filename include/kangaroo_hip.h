@@ -135,7 +135,8 @@ int kg_session_destroy(kg_session* s);
  * 1 when head_dim >= 32 and t_max % 32 == 0), "prefill_rows", or a tuning key; -1 if unknown. */
 int kg_session_get(kg_session* s, const char* key);
 /* tuning knobs: "attn_nsplit" (number of fixed key chunks: fixes the boundaries of the attention
- * reduction), "attn_blocks" (blocks that share one head's chunks; geometry only);
+ * reduction), "attn_blocks" (blocks that share one head's chunks) and "attn_teams" (1 or 2 four-wave teams per
+ * block working on different chunks at once): geometry only, results do not change;
  * "<mode>_waves" and "<mode>_blocks_per_cu" for all linear ops of a mode, or "<mode>.<op>.waves" /
  * "<mode>.<op>.blocks_per_cu" for one, with mode in {vec (1 row), mfma (2..16 rows)} and op in
  * {qkv, o, gateup, down, head}; "persist" (2: run the verify pass and the deep layers of plain

@@ -15,7 +15,7 @@
 #include "kg_attn_body.h"
 
 #define ATT_U 4         // K and V loads in flight per lane per batch
-#define KG_ATTN_DYN_LDS (120 * 1024)   // dynamic LDS the MFMA kernel may ask for, beside its static team buffers
+#define KG_ATTN_PART_LDS (68 * 1024)   // LDS for a block's local chunk partials (8 chunks x 16 rows x 130 floats), beside its team buffers
 
 // Called by every thread of a block after its partial stores.  Returns true in all threads
 // of the block that completed the head's set of n_act partials (and re-arms the counter).
@@ -195,20 +195,23 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_kernel(const KgAttnArgs a
 // MFMA variant (head_dim 32 / 64 / 128, V cached transposed [Hkv][hd][t_max]).
 //
 // The keys are cut into fixed chunks (boundaries depend on t_max and nsplit only); a chunk is
-// worked on by the 4 waves of a block (32-key tiles, wave w takes tiles w, w+4, ...), whose
+// worked on by a team of 4 waves (32-key tiles, wave w takes tiles w, w+4, ...), whose
 // results meet in LDS: that gives one partial (max, sum, acc) per chunk and query row, and
 // the final rows are the merge of the chunk partials in chunk order.  This arithmetic is the
-// same however the chunks are spread over blocks.  A block owns `cpb` consecutive chunks of
-// one head and walks them with the next tile's K/V already requested while the current one
-// is computed.  If the chunks in use fit one block (contexts up to cpb * chunk keys) their
-// partials stay in LDS and the block writes the final rows itself: no global partials, no
-// counter, no second round trip.  Otherwise the partials go to memory and the block that
-// arrives last at the head's counter merges them.
-template <int DT, int HD>
-__global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnArgs a) {
+// same however the chunks are spread over teams and blocks.  A block owns `cpb` consecutive
+// chunks of one head; its NT teams take them in turn (team t: chunks t, t + NT, ...) and walk
+// them with the next tile's K/V already requested while the current one is computed.  If the
+// chunks in use fit one block (contexts up to cpb * chunk keys) their partials stay in LDS and
+// the block writes the final rows itself: no global partials, no counter, no further memory
+// round trips.  Otherwise the partials go to memory and the block that arrives last at the
+// head's counter merges them (a chain of four round trips, ~6 us).
+template <int DT, int HD, int NT>
+__global__ void __launch_bounds__(NT * ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnArgs a) {
     typedef KgT<DT> T;
     const KgDyn* dyn = a.dyn;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int team = __builtin_amdgcn_readfirstlane(tid / (ATT_NW * 64)), ttid = tid % (ATT_NW * 64);
+    const int wave = __builtin_amdgcn_readfirstlane(ttid >> 6);
     const int c = lane & 15, g = lane >> 4;
     // blockIdx.z selects a block of 16 query rows (prefill passes carry up to KG_GEMM_ROWS rows);
     // rows of a pass sit at consecutive positions
@@ -228,12 +231,14 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnA
     if (c0 >= n_act) return;
     const int nblk_act = (n_act + cpb - 1) / cpb;  // blocks of this head that have chunks
     const bool local = (nblk_act == 1);
+    const int nit = (c1 - c0 + NT - 1) / NT;       // chunk rounds of this block (same for every team)
 
     constexpr int KS = HD / 32, DB = HD / 16;
-    __shared__ KgAttnTeamLds<HD> lds;
-    extern __shared__ __attribute__((aligned(16))) float pl[];      // local partials: [cpb][M][HD] then [cpb][M][2]
-    float* pl_o = pl;
-    float* pl_ml = pl + (size_t)cpb * M * HD;
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    KgAttnTeamLds<HD>* lds_all = (KgAttnTeamLds<HD>*)smem_;
+    KgAttnTeamLds<HD>& lds = lds_all[team];
+    float* pl_o = (float*)(smem_ + NT * sizeof(KgAttnTeamLds<HD>));   // local partials: [cpb][M][HD] then [cpb][M][2]
+    float* pl_ml = pl_o + (size_t)cpb * M * HD;
 
     const int kvh = h / (a.H / a.Hkv);
     const int lim = (c < M) ? pos_c : -1;          // causal bound of this lane's query column
@@ -248,17 +253,24 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnA
         qf[s] = __builtin_amdgcn_raw_buffer_load_b128(qr, (unsigned)((((size_t)(row0 + c) * a.H + h) * HD + 32 * s + 8 * g) * 2), 0, 0);
     const float inv_scale = sqrtf((float)HD);
 
-    // prefetch cursor over this wave's tiles: (chunk pc, first key ptb)
-    int pc = c0, ptb = c0 * chunk + 32 * wave;
+    // prefetch cursor over this wave's tiles: (chunk round pk, first key ptb)
+    int pk = 0, ptb = (c0 + team) * chunk + 32 * wave;
     auto settle = [&]() {
-        while (pc < c1 && ptb >= min(len, pc * chunk + chunk)) { ++pc; ptb = pc * chunk + 32 * wave; }
+        while (pk < nit) {
+            const int ch = c0 + team + NT * pk;
+            if (ch < c1 && ptb < min(len, ch * chunk + chunk)) break;
+            ++pk;
+            ptb = (c0 + team + NT * pk) * chunk + 32 * wave;
+        }
     };
     settle();
     KgAttnTile<HD> nxt;
-    if (pc < c1) attn_tile_load<HD, 0>(nxt, kr, vr, a.t_max, ptb, lane);
+    if (pk < nit) attn_tile_load<HD, 0>(nxt, kr, vr, a.t_max, ptb, lane);
 
-    for (int ch = c0; ch < c1; ++ch) {
-        const int tbeg = ch * chunk, tend = min(len, tbeg + chunk);
+    for (int k = 0; k < nit; ++k) {
+        const int ch = c0 + team + NT * k;
+        const bool valid = ch < c1;                // team-uniform; a team without a chunk only keeps the barriers company
+        const int tbeg = ch * chunk, tend = valid ? min(len, tbeg + chunk) : tbeg;
         float mrun = -INFINITY, lsum = 0.f;
         kg_f4 O[DB];
 #pragma unroll
@@ -267,48 +279,52 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnA
             const KgAttnTile<HD> cur = nxt;        // == tile (ch, tb): the cursor visits tiles in this order
             ptb += 32 * ATT_NW;
             settle();
-            if (pc < c1) attn_tile_load<HD, 0>(nxt, kr, vr, a.t_max, ptb, lane);
+            if (pk < nit) attn_tile_load<HD, 0>(nxt, kr, vr, a.t_max, ptb, lane);
             attn_tile_compute<DT, HD>(cur, qf, tb, tend, lim, inv_scale, lane, mrun, lsum, O);
         }
         lsum += __shfl_xor(lsum, 16, 64);
         lsum += __shfl_xor(lsum, 32, 64);
-        // ---- merge the waves of this chunk through LDS ----
+        // ---- merge the waves of this chunk through the team's LDS ----
+        if (valid) {
 #pragma unroll
-        for (int b = 0; b < DB; ++b)
+            for (int b = 0; b < DB; ++b)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lds.o[wave][4 * g + i][16 * b + c] = O[b][i];
-        if (g == 0) { lds.ml[wave][c][0] = mrun; lds.ml[wave][c][1] = lsum; }
+                for (int i = 0; i < 4; ++i) lds.o[wave][4 * g + i][16 * b + c] = O[b][i];
+            if (g == 0) { lds.ml[wave][c][0] = mrun; lds.ml[wave][c][1] = lsum; }
+        }
         __syncthreads();
-        for (int i = tid; i < M * HD; i += ATT_NW * 64) {
-            const int m = i / HD, dmi = i - m * HD;
-            float mx = -INFINITY;
+        if (valid) {
+            for (int i = ttid; i < M * HD; i += ATT_NW * 64) {
+                const int m = i / HD, dmi = i - m * HD;
+                float mx = -INFINITY;
 #pragma unroll
-            for (int w = 0; w < ATT_NW; ++w) mx = fmaxf(mx, lds.ml[w][m][0]);
-            float o = 0.f, l = 0.f;
+                for (int w = 0; w < ATT_NW; ++w) mx = fmaxf(mx, lds.ml[w][m][0]);
+                float o = 0.f, l = 0.f;
 #pragma unroll
-            for (int w = 0; w < ATT_NW; ++w) {
-                const float wm = lds.ml[w][m][0];
-                const float fw = (wm == -INFINITY) ? 0.f : expf(wm - mx);
-                o += fw * lds.o[w][m][dmi];
-                l += fw * lds.ml[w][m][1];
-            }
-            if (local) {
-                pl_o[((size_t)(ch - c0) * M + m) * HD + dmi] = o;
-                if (dmi == 0) { pl_ml[((ch - c0) * M + m) * 2] = mx; pl_ml[((ch - c0) * M + m) * 2 + 1] = l; }
-            } else {
-                coh_store(a.part_o + (((size_t)ch * a.max_rows + row0 + m) * a.H + h) * HD + dmi, o);
-                if (dmi == 0) {
-                    float* ml = a.part_ml + (((size_t)ch * a.max_rows + row0 + m) * a.H + h) * 2;
-                    coh_store(ml, mx); coh_store(ml + 1, l);
+                for (int w = 0; w < ATT_NW; ++w) {
+                    const float wm = lds.ml[w][m][0];
+                    const float fw = (wm == -INFINITY) ? 0.f : expf(wm - mx);
+                    o += fw * lds.o[w][m][dmi];
+                    l += fw * lds.ml[w][m][1];
+                }
+                if (local) {
+                    pl_o[((size_t)(ch - c0) * M + m) * HD + dmi] = o;
+                    if (dmi == 0) { pl_ml[((ch - c0) * M + m) * 2] = mx; pl_ml[((ch - c0) * M + m) * 2 + 1] = l; }
+                } else {
+                    coh_store(a.part_o + (((size_t)ch * a.max_rows + row0 + m) * a.H + h) * HD + dmi, o);
+                    if (dmi == 0) {
+                        float* ml = a.part_ml + (((size_t)ch * a.max_rows + row0 + m) * a.H + h) * 2;
+                        coh_store(ml, mx); coh_store(ml + 1, l);
+                    }
                 }
             }
         }
-        __syncthreads();                           // lds is free for the next chunk; local partials are visible
+        __syncthreads();                           // team LDS is free for the next chunk; local partials are visible
     }
     if (local) {
         // same merge as split_combine, partials read from LDS
         const int ns = c1 - c0;
-        for (int i = tid; i < M * HD; i += ATT_NW * 64) {
+        for (int i = tid; i < M * HD; i += NT * ATT_NW * 64) {
             const int m = i / HD, dmi = i - m * HD;
             float mx = -INFINITY;
             for (int s = 0; s < ns; ++s) mx = fmaxf(mx, pl_ml[(s * M + m) * 2]);
@@ -324,7 +340,7 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_mfma_kernel(const KgAttnA
         return;
     }
     const bool last = split_arrive(a.counters + blockIdx.z * a.H + h, nblk_act);
-    split_combine<DT, false>(a, h, HD, row0, M, n_act, tid, ATT_NW * 64, lds.cl, last);
+    split_combine<DT, false>(a, h, HD, row0, M, n_act, tid, NT * ATT_NW * 64, lds_all[0].cl, last);
 }
 
 template <int DT, int LPR>
@@ -342,15 +358,21 @@ static int launch_dt(const KgAttnArgs& a, hipStream_t st) {
     if (a.v_transposed) {
         const int nby = a.blocks_per_head < 1 ? 1 : (a.blocks_per_head > a.nsplit ? a.nsplit : a.blocks_per_head);
         const int cpb = (a.nsplit + nby - 1) / nby;
+        const int nt = (a.teams == 2 && cpb >= 2) ? 2 : 1;          // a second team only pays with several chunks per block
         dim3 grid(a.H, nby, (a.max_rows + 15) / 16);
-        const size_t smem = (size_t)cpb * (a.max_rows < 16 ? a.max_rows : 16) * (a.hd + 2) * sizeof(float);
-        if (smem > (size_t)KG_ATTN_DYN_LDS) return -1;
+        const size_t part = (size_t)cpb * (a.max_rows < 16 ? a.max_rows : 16) * (a.hd + 2) * sizeof(float);
+        if (part > (size_t)KG_ATTN_PART_LDS) return -1;
+#define KG_ATTN_LAUNCH(HD_) do { \
+            const size_t smem = part + nt * sizeof(KgAttnTeamLds<HD_>); \
+            if (nt == 2) hipLaunchKernelGGL((kg_attn_mfma_kernel<DT, HD_, 2>), grid, dim3(2 * ATT_NW * 64), smem, st, a); \
+            else hipLaunchKernelGGL((kg_attn_mfma_kernel<DT, HD_, 1>), grid, dim3(ATT_NW * 64), smem, st, a); } while (0)
         switch (a.hd) {
-        case 32: hipLaunchKernelGGL((kg_attn_mfma_kernel<DT, 32>), grid, dim3(ATT_NW * 64), smem, st, a); break;
-        case 64: hipLaunchKernelGGL((kg_attn_mfma_kernel<DT, 64>), grid, dim3(ATT_NW * 64), smem, st, a); break;
-        case 128: hipLaunchKernelGGL((kg_attn_mfma_kernel<DT, 128>), grid, dim3(ATT_NW * 64), smem, st, a); break;
+        case 32: KG_ATTN_LAUNCH(32); break;
+        case 64: KG_ATTN_LAUNCH(64); break;
+        case 128: KG_ATTN_LAUNCH(128); break;
         default: return -1;
         }
+#undef KG_ATTN_LAUNCH
     } else {
         switch (a.hd) {
         case 16: launch_lpr<DT, 2>(a, st); break;
@@ -364,14 +386,13 @@ static int launch_dt(const KgAttnArgs& a, hipStream_t st) {
 }
 
 // One-time opt-in for > 64 KiB of LDS (team buffers + local chunk partials of 16-row passes).
+template <int DT, int HD> static void attn_set_attr() {
+    (void)hipFuncSetAttribute((const void*)kg_attn_mfma_kernel<DT, HD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KG_ATTN_PART_LDS + sizeof(KgAttnTeamLds<HD>)));
+    (void)hipFuncSetAttribute((const void*)kg_attn_mfma_kernel<DT, HD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KG_ATTN_PART_LDS + 2 * sizeof(KgAttnTeamLds<HD>)));
+}
 void kg_attn_init() {
-    const int lim = KG_ATTN_DYN_LDS;
-    (void)hipFuncSetAttribute((const void*)kg_attn_mfma_kernel<KG_F16, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)kg_attn_mfma_kernel<KG_F16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)kg_attn_mfma_kernel<KG_F16, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)kg_attn_mfma_kernel<KG_BF16, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)kg_attn_mfma_kernel<KG_BF16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)kg_attn_mfma_kernel<KG_BF16, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    attn_set_attr<KG_F16, 32>(); attn_set_attr<KG_F16, 64>(); attn_set_attr<KG_F16, 128>();
+    attn_set_attr<KG_BF16, 32>(); attn_set_attr<KG_BF16, 64>(); attn_set_attr<KG_BF16, 128>();
     (void)hipGetLastError();
 }
 

@@ -53,7 +53,7 @@ struct kg_session {
     // tuning
     // launch geometry per (mode: 0 GEMV / 1 MFMA, op: qkv, o, gateup, down, head)
     int waves[2][5], bpc[2][5];
-    int attn_nsplit, attn_blocks;
+    int attn_nsplit, attn_blocks, attn_teams;
     int v_transposed;
     // persistent pass kernel: phase programs [0] verify pass, [1] deep layers of plain decoding
     int persist;                       // 1: multi-row passes of the loop run as one persistent kernel
@@ -171,6 +171,7 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     s->v_transposed = (shape->head_dim >= 32 && buffers->t_max % 32 == 0) ? 1 : 0;
     s->attn_nsplit = 16;
     s->gemm_prefill = s->v_transposed;           // the 64-row passes need the MFMA attention kernel
+    s->attn_teams = 1;
     s->attn_blocks = 16;                         // one chunk per block: long contexts need many CUs pulling K/V (one CU sustains only ~60 GB/s)
     s->round_graph = nullptr; s->round_graph_steps = -1; s->vanilla_graph = nullptr;
     s->prog_n[0] = s->prog_n[1] = s->prog_n[2] = 0;
@@ -213,6 +214,7 @@ extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
     bool done = false;
     if (k == "attn_nsplit") { if (value > 32) return fail(-1, "nsplit <= 32"); s->attn_nsplit = value; done = true; }
     if (k == "gemm_prefill") { s->gemm_prefill = (value >= 2 && s->v_transposed) ? 1 : 0; done = true; }   // 1: off, 2: on
+    if (k == "attn_teams") { if (value > 2) return fail(-1, "attn_teams is 1 or 2"); s->attn_teams = value; done = true; }
     if (k == "attn_blocks") { if (value > 32) return fail(-1, "attn_blocks <= 32"); s->attn_blocks = value; done = true; }
     if (k == "persist") { s->persist = (value >= 2 && s->v_transposed && (g_ncu % 8) == 0) ? 1 : 0; done = true; }   // 1: off, 2: on
     for (int op = 0; op < 5 && !done; ++op)
@@ -247,6 +249,7 @@ extern "C" int kg_session_get(kg_session* s, const char* key) {
     }
     if (k == "attn_nsplit") return s->attn_nsplit;
     if (k == "attn_blocks") return s->attn_blocks;
+    if (k == "attn_teams") return s->attn_teams;
     if (k == "gemm_prefill") return s->gemm_prefill;
     if (k == "persist") return s->persist;
     if (k == "prefill_rows") return s->prefill_rows;
@@ -300,7 +303,7 @@ static int run_layer(kg_session* s, const kg_layer_weights& lw, void* kc, void* 
         memset(&a, 0, sizeof(a));
         a.dyn = dyn; a.q = s->xq; a.k_cache = kc; a.v_cache = vc;
         a.H = sh.num_heads; a.Hkv = sh.num_kv_heads; a.hd = sh.head_dim; a.t_max = s->buf.t_max; a.v_transposed = s->v_transposed;
-        a.nsplit = s->attn_nsplit; a.blocks_per_head = s->attn_blocks; a.part_o = s->part_o; a.part_ml = s->part_ml; a.counters = s->attn_counters; a.out = s->attn_out; a.max_rows = max_rows;
+        a.nsplit = s->attn_nsplit; a.blocks_per_head = s->attn_blocks; a.teams = s->attn_teams; a.part_o = s->part_o; a.part_ml = s->part_ml; a.counters = s->attn_counters; a.out = s->attn_out; a.max_rows = max_rows;
         KG_TRY(kg_launch_attn(a, dt, st));
     }
     const bool attn_only = (lw.wgu == nullptr);
@@ -493,7 +496,7 @@ static int build_program(kg_session* s, int which, const KgDyn* dyn, int max_row
             KgAttnArgs& a = p.attn;
             a.dyn = dyn; a.q = xq; a.k_cache = layer_k(s, l); a.v_cache = layer_v(s, l);
             a.H = sh.num_heads; a.Hkv = sh.num_kv_heads; a.hd = sh.head_dim; a.t_max = s->buf.t_max; a.v_transposed = 1;
-            a.nsplit = s->attn_nsplit; a.blocks_per_head = s->attn_blocks; a.part_o = s->part_o; a.part_ml = s->part_ml; a.counters = s->attn_counters; a.out = ao; a.max_rows = max_rows;
+            a.nsplit = s->attn_nsplit; a.blocks_per_head = s->attn_blocks; a.teams = s->attn_teams; a.part_o = s->part_o; a.part_ml = s->part_ml; a.counters = s->attn_counters; a.out = ao; a.max_rows = max_rows;
             prog.push_back(p);
         }
         {
@@ -644,7 +647,7 @@ static int run_layer_gemm(kg_session* s, const kg_layer_weights& lw, void* kc, v
         memset(&a, 0, sizeof(a));
         a.dyn = dyn; a.q = s->pf_xq; a.k_cache = kc; a.v_cache = vc;
         a.H = sh.num_heads; a.Hkv = sh.num_kv_heads; a.hd = sh.head_dim; a.t_max = s->buf.t_max; a.v_transposed = s->v_transposed;
-        a.nsplit = s->attn_nsplit; a.blocks_per_head = s->attn_blocks; a.part_o = s->part_o; a.part_ml = s->part_ml; a.counters = s->attn_counters;
+        a.nsplit = s->attn_nsplit; a.blocks_per_head = s->attn_blocks; a.teams = s->attn_teams; a.part_o = s->part_o; a.part_ml = s->part_ml; a.counters = s->attn_counters;
         a.out = s->pf_ao; a.max_rows = KG_GEMM_ROWS;
         KG_TRY(kg_launch_attn(a, dt, st));
     }
@@ -959,7 +962,7 @@ extern "C" int kg_attention(int dtype, const void* q, int n_rows, int pos0, cons
     KgAttnArgs a;
     memset(&a, 0, sizeof(a));
     a.dyn = dyn; a.q = q; a.k_cache = k_cache; a.v_cache = v_cache; a.H = n_heads; a.Hkv = n_kv_heads; a.hd = head_dim; a.t_max = t_max; a.v_transposed = v_transposed ? 1 : 0;
-    a.nsplit = nsplit; a.blocks_per_head = nsplit; a.max_rows = n_rows;
+    a.nsplit = nsplit; a.blocks_per_head = nsplit; a.teams = 1; a.max_rows = n_rows;
     a.part_o = (float*)((char*)scratch + 256);
     a.part_ml = a.part_o + (size_t)nsplit * KG_GEMM_ROWS * n_heads * head_dim;
     a.counters = (unsigned*)(((uintptr_t)(a.part_ml + (size_t)nsplit * KG_GEMM_ROWS * n_heads * 2) + 255) & ~(uintptr_t)255);

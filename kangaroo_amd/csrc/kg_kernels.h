@@ -44,6 +44,7 @@ struct KgAttnArgs {
     int v_transposed;           // 1: v_cache is [Hkv, hd, t_max] and the MFMA kernel runs (hd 32/64/128, t_max % 32 == 0)
     int nsplit;                 // number of fixed key chunks the cache is cut into
     int blocks_per_head;        // MFMA kernel: blocks that share the chunks of one head (launch geometry only)
+    int teams;                  // MFMA kernel: 2 = two 4-wave teams per block work on different chunks at once (geometry only)
     float* part_o;              // [nsplit][rows][H][hd]
     float* part_ml;             // [nsplit][rows][H][2]
     unsigned* counters;         // [4][H] arrival counters of the split merge; zero between launches

@@ -305,3 +305,24 @@ def test_full_size_7b_losslessness_and_determinism():
         assert new - 1 - 6 <= st.new_tokens <= new
     del model, eng
     torch.cuda.empty_cache()
+
+
+def test_attention_geometry_does_not_change_results():
+    """Blocks per head and teams per block only decide which block/team works on which key chunk;
+    the chunk partials and their merge order are fixed, so outputs are bit-identical."""
+    shape = get_shape("tinyllama-1.1b")
+    shape = type(shape)(**{**shape.to_dict(), "num_hidden_layers": 4})
+    base, adapter = synth_state_dicts(shape, 2, seed=51, dtype=torch.float16, recipe=Recipe.agreeable(0.3, 8.0))
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, 2)
+    eng = model.engine
+    g = torch.Generator().manual_seed(6)
+    ids = torch.randint(3, shape.vocab_size, (700,), generator=g)
+    ref = None
+    for blocks, teams in ((16, 1), (2, 2), (4, 2), (2, 1), (1, 2)):
+        eng.set_tuning(attn_blocks=blocks, attn_teams=teams)
+        out, st = eng.generate(ids, 80, mode="kangaroo")
+        if ref is None:
+            ref = (out, st.accept_lengths, st.draft_lengths)
+        else:
+            assert (out, st.accept_lengths, st.draft_lengths) == ref, (blocks, teams)
+    eng.set_tuning(attn_blocks=16, attn_teams=1)
