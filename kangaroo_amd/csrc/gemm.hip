@@ -16,9 +16,6 @@
 #ifndef GEMM_KB
 #define GEMM_KB 4                   // weight tiles (32 k each) per k-batch
 #endif
-#ifndef GEMM_RING
-#define GEMM_RING 8                 // weight batches per wave: GEMM_RING - 1 in flight
-#endif
 #define GEMM_XROW (GEMM_KB * 64)    // bytes of one X row of a k-batch in LDS: exactly one 256-byte bank row
 // 16-byte piece p of row `row` sits at piece slot p ^ (row & 15): the 16 lanes ds_read_b128 serves
 // together read 16 different rows at (nearly) one column, which the XOR spreads over all 16 slots.
@@ -117,36 +114,39 @@ __global__ void __launch_bounds__(GEMM_NW * 64) kg_gemm_kernel(const KgLinArgs a
             for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) acc[cb] = T::mfma(wv[u], x[u][cb], acc[cb]);
     };
 
-    // Software pipeline.  Weights: ring of GEMM_RING register batches, all but one in flight (a
-    // CU runs one or two blocks here, so the bytes in flight per wave have to cover the HBM
-    // latency on their own).  X: batch b sits in LDS buffer b & 1; batches b+1 and b+2 are on
-    // their way in two register sets, and a set is stored to LDS one step after it was asked for.
-    constexpr int D = GEMM_RING;
-    static_assert(D % 2 == 0, "the ring is unrolled together with the two X register sets");
+    // Software pipeline.  Weights: ring of D register batches, all but one in flight (a CU runs
+    // one or two blocks here, so the bytes in flight per wave have to cover the HBM latency on
+    // their own).  X: batch b sits in LDS buffer b & 1; batches b+1 .. b+XS are on their way in XS
+    // register sets (an L2 round trip is several step times), and the set holding X(b+1) is
+    // stored to LDS behind the MFMAs of step b.
+    constexpr int D = (GEMM_NW == 4) ? 6 : 8;
+    constexpr int XS = (GEMM_NW == 4) ? 3 : 2;
+    constexpr int U = (D % XS == 0) ? D : D * XS;       // steps per unrolled round: a multiple of D, XS and 2
+    static_assert(U % D == 0 && U % XS == 0 && U % 2 == 0, "ring indices must repeat every unrolled round");
     kg_u4 w[D][GEMM_KB];
-    kg_u4 sx0[GEMM_STAGE], sx1[GEMM_STAGE], gw0 = {0u, 0u, 0u, 0u}, gw1 = {0u, 0u, 0u, 0u};
-    stage_load(sx0, gw0, 0);
+    kg_u4 sx[XS][GEMM_STAGE], gw[XS];
+#pragma unroll
+    for (int i = 0; i < XS; ++i) gw[i] = kg_u4{0u, 0u, 0u, 0u};
+    stage_load(sx[0], gw[0], 0);
     issue_w(w[0], 0);
-    stage_load(sx1, gw1, 1);
+#pragma unroll
+    for (int i = 1; i < XS; ++i) stage_load(sx[i], gw[i], i);
 #pragma unroll
     for (int i = 1; i < D - 1; ++i) issue_w(w[i], i);
-    stage_store(sx0, gw0, xs0);
-    stage_load(sx0, gw0, 2);
+    stage_store(sx[0], gw[0], xs0);
+    stage_load(sx[0], gw[0], XS);
     __syncthreads();
     // step b: weights W(b) in wc; wr is the ring slot freed by step b-1; (sxe, gwe) holds X(b+1)
     auto step = [&](kg_u4 (&wc)[GEMM_KB], kg_u4 (&wr)[GEMM_KB], kg_u4 (&sxe)[GEMM_STAGE], kg_u4& gwe, int b) {
         issue_w(wr, b + D - 1);
         compute(wc, (b & 1) ? xs1 : xs0);
         stage_store(sxe, gwe, (b & 1) ? xs0 : xs1);
-        stage_load(sxe, gwe, b + 3);
+        stage_load(sxe, gwe, b + 1 + XS);
         __syncthreads();
     };
-    for (int b = 0; b < NB; b += D) {      // batches past the last one: zeros in, zeros added
+    for (int b = 0; b < NB; b += U) {      // batches past the last one: zeros in, zeros added
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            if (i & 1) step(w[i], w[(i + D - 1) % D], sx0, gw0, b + i);
-            else step(w[i], w[(i + D - 1) % D], sx1, gw1, b + i);
-        }
+        for (int i = 0; i < U; ++i) step(w[i % D], w[(i + D - 1) % D], sx[(i + 1) % XS], gw[(i + 1) % XS], b + i);
     }
 
     // ---- row factors of the deferred RMSNorm ----
