@@ -156,12 +156,14 @@ def test_logits_against_golden():
     ("small", 2, Recipe.agreeable(0.3, 8.0), 11),
     ("small", 3, Recipe(), 12),
     ("tinyllama-1.1b", 2, Recipe.agreeable(0.2, 10.0), 13),
+    ("tinyllama-1.1b-full", 2, Recipe.agreeable(0.2, 10.0), 14),
 ])
 def test_against_live_oracle(shape_name, L, recipe, seed):
     """Larger shapes than the fixtures: oracle (fp32 CPU) and device on the same weights."""
-    shape = get_shape(shape_name)
+    shape = get_shape(shape_name.replace("-full", ""))
     if shape_name == "tinyllama-1.1b":
         shape = type(shape)(**{**shape.to_dict(), "num_hidden_layers": 4})     # same layer shape, 4 layers: seconds on the CPU
+    # "-full": all 22 layers, the reference's own CPU-runnable configuration (about half a minute of fp32 CPU work)
     base, adapter = synth_state_dicts(shape, L, seed=seed, dtype=torch.float16, recipe=recipe)
     model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, L)
     om = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), base, adapter, L)
