@@ -141,7 +141,9 @@ int kg_session_get(kg_session* s, const char* key);
  * "<mode>.<op>.blocks_per_cu" for one, with mode in {vec (1 row), mfma (2..16 rows)} and op in
  * {qkv, o, gateup, down, head}; "persist" (2: run the verify pass and the deep layers of plain
  * decoding as one persistent kernel with grid barriers, 1: one kernel per op, the default) and
- * "persist.<op>.waves".  Block counts never change results; wave counts set how K is split
+ * "persist.<op>.waves"; "accept_top_k" (1: greedy acceptance, evaluation/inference_kangaroo.py:95-104;
+ * k > 1: a drafted token is kept while it is among the k largest verify logits of its row,
+ * evaluation/inference_kangaroo_MTBench.py:377-389).  Block counts never change results; wave counts set how K is split
  * inside a block and therefore the fp32 summation order.  Values must be >= 1.
  * kg_session_get reads the per-op keys and "persist" (0 / 1) back. */
 int kg_session_set(kg_session* s, const char* key, int value);

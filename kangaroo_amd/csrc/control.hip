@@ -221,8 +221,32 @@ __global__ void kg_verify_begin_kernel(KgLoopBufs b) {
     if (i < KG_MAX_ROWS) d->pos[i] = s + i;
 }
 
-// greedy accept / reject, cache rollback by length (:91-119)
-__global__ void kg_accept_kernel(KgLoopBufs b, const float* head_part, int stride, int nblocks) {
+// Top-k verification (evaluation/inference_kangaroo_MTBench.py:377-389): rank[i] = how many verify
+// logits of row i are larger than the logit of the token drafted for position s+1+i.  The drafted
+// token is among the k largest iff rank < k.  One block per row; logits are the stored 16-bit rows.
+template <int DT>
+__global__ void kg_topk_rank_kernel(KgLoopBufs b, const unsigned short* logits, int vocab, int* rank) {
+    typedef KgT<DT> T;
+    __shared__ int s_cnt[4];
+    const int* st = b.state;
+    if (st[KS_ALIVE] == 0) return;
+    const int s = st[KS_START], q = st[KS_END] - s;
+    const int i = blockIdx.x;
+    if (i >= q - 1) return;                              // the last row has no drafted successor
+    const unsigned short* row = logits + (size_t)i * vocab;
+    const float lt = T::to_f(row[b.tokens[s + 1 + i]]);
+    int cnt = 0;
+    for (int v = threadIdx.x; v < vocab; v += blockDim.x) cnt += (T::to_f(row[v]) > lt) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) rank[i] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// accept / reject, cache rollback by length (:91-119).  top_k == 1: the greedy rule of :97; top_k > 1:
+// a drafted token survives while rank[i] < top_k (kg_topk_rank_kernel).
+__global__ void kg_accept_kernel(KgLoopBufs b, const float* head_part, int stride, int nblocks, const int* rank, int top_k) {
     __shared__ float s_mx[8], s_sum[8]; __shared__ int s_idx[8];
     __shared__ int s_tok[KG_MAX_ROWS];
     int* st = b.state;
@@ -246,7 +270,8 @@ __global__ void kg_accept_kernel(KgLoopBufs b, const float* head_part, int strid
         int snew = s, stop = 0;
         for (int i = 0; i < q; ++i) {
             const int o = s_tok[i];
-            if (i == q - 1 || o == eos || o != b.tokens[s + 1 + i]) {                 // :97
+            const bool rejected = (i == q - 1) ? true : (top_k > 1 ? rank[i] >= top_k : o != b.tokens[s + 1 + i]);
+            if (i == q - 1 || o == eos || rejected) {                                 // :97
                 b.tokens[s + 1 + i] = o;                                              // :98
                 snew = s + 1 + i;                                                     // :99
                 stop = (o == eos);                                                    // :100
@@ -296,6 +321,11 @@ int kg_launch_round_begin(const KgLoopBufs& b, hipStream_t st) { KG_L1(kg_round_
 int kg_launch_step_mid(const KgLoopBufs& b, int step, hipStream_t st) { KG_L1(kg_step_mid_kernel, b, step); }
 int kg_launch_step_end(const KgLoopBufs& b, int step, const float* head_part, int nblocks, hipStream_t st) { KG_L1(kg_step_end_kernel, b, step, head_part, nblocks); }
 int kg_launch_verify_begin(const KgLoopBufs& b, hipStream_t st) { KG_L1(kg_verify_begin_kernel, b); }
-int kg_launch_accept(const KgLoopBufs& b, const float* head_part, int stride, int nblocks, hipStream_t st) { KG_L1(kg_accept_kernel, b, head_part, stride, nblocks); }
+int kg_launch_accept(const KgLoopBufs& b, const float* head_part, int stride, int nblocks, const int* rank, int top_k, hipStream_t st) { KG_L1(kg_accept_kernel, b, head_part, stride, nblocks, rank, top_k); }
+int kg_launch_topk_rank(const KgLoopBufs& b, const void* logits, int vocab, int* rank, int dtype, hipStream_t st) {
+    if (dtype == KG_F16) hipLaunchKernelGGL(kg_topk_rank_kernel<KG_F16>, dim3(KG_MAX_ROWS), dim3(256), 0, st, b, (const unsigned short*)logits, vocab, rank);
+    else hipLaunchKernelGGL(kg_topk_rank_kernel<KG_BF16>, dim3(KG_MAX_ROWS), dim3(256), 0, st, b, (const unsigned short*)logits, vocab, rank);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 int kg_launch_vanilla_begin(const KgLoopBufs& b, hipStream_t st) { KG_L1(kg_vanilla_begin_kernel, b); }
 int kg_launch_vanilla_end(const KgLoopBufs& b, const float* head_part, int nblocks, hipStream_t st) { KG_L1(kg_vanilla_end_kernel, b, head_part, nblocks); }

@@ -48,6 +48,8 @@ struct kg_session {
     float *part_o, *part_ml, *head_part;
     unsigned* attn_counters;
     int* head_tok; float* head_pmax;
+    char* vlogits; int* topk_rank;     // verify logits rows and rank of each drafted token (top-k verification)
+    int accept_top_k;                  // 1: greedy acceptance
     int head_part_stride;
     int prefill_rows;
     // tuning
@@ -111,6 +113,8 @@ static void carve(kg_session* s, Carver& c, const kg_shape* sh, int t_max) {
     float* head_part = c.take<float>((size_t)R * hp_stride * 4);
     int* head_tok = c.take<int>(R);
     float* head_pmax = c.take<float>(R);
+    char* vlogits = c.take<char>(R * (size_t)sh->vocab_size * e);
+    int* topk_rank = c.take<int>(R);
     const int prog_cap = 5 * sh->num_layers + 2;
     KgPhase* prog0 = c.take<KgPhase>(prog_cap);
     KgPhase* prog1 = c.take<KgPhase>(prog_cap);
@@ -133,7 +137,7 @@ static void carve(kg_session* s, Carver& c, const kg_shape* sh, int t_max) {
         s->h = h; s->h2 = h2; s->xq = xq; s->attn_out = attn_out; s->act = act; s->exited = exited;
         s->prev_exit = prev_exit; s->adapter_in = adapter_in; s->adapter_h = adapter_h; s->hs_early = hs_early;
         s->part_o = part_o; s->part_ml = part_ml; s->attn_counters = attn_counters; s->head_part = head_part; s->head_part_stride = hp_stride;
-        s->head_tok = head_tok; s->head_pmax = head_pmax;
+        s->head_tok = head_tok; s->head_pmax = head_pmax; s->vlogits = vlogits; s->topk_rank = topk_rank;
     }
 }
 
@@ -170,6 +174,7 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     s->waves[1][3] = 2;                          // down_proj in the large-K MFMA mode
     s->v_transposed = (shape->head_dim >= 32 && buffers->t_max % 32 == 0) ? 1 : 0;
     s->attn_nsplit = 16;
+    s->accept_top_k = 1;
     s->gemm_prefill = s->v_transposed;           // the 64-row passes need the MFMA attention kernel
     s->attn_teams = 1;
     s->attn_blocks = 16;                         // one chunk per block: long contexts need many CUs pulling K/V (one CU sustains only ~60 GB/s)
@@ -214,6 +219,7 @@ extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
     bool done = false;
     if (k == "attn_nsplit") { if (value > 32) return fail(-1, "nsplit <= 32"); s->attn_nsplit = value; done = true; }
     if (k == "gemm_prefill") { s->gemm_prefill = (value >= 2 && s->v_transposed) ? 1 : 0; done = true; }   // 1: off, 2: on
+    if (k == "accept_top_k") { if (value > s->sh.vocab_size) return fail(-1, "accept_top_k <= vocab_size"); s->accept_top_k = value; done = true; }
     if (k == "attn_teams") { if (value > 2) return fail(-1, "attn_teams is 1 or 2"); s->attn_teams = value; done = true; }
     if (k == "attn_blocks") { if (value > 32) return fail(-1, "attn_blocks <= 32"); s->attn_blocks = value; done = true; }
     if (k == "persist") { s->persist = (value >= 2 && s->v_transposed && (g_ncu % 8) == 0) ? 1 : 0; done = true; }   // 1: off, 2: on
@@ -250,6 +256,7 @@ extern "C" int kg_session_get(kg_session* s, const char* key) {
     if (k == "attn_nsplit") return s->attn_nsplit;
     if (k == "attn_blocks") return s->attn_blocks;
     if (k == "attn_teams") return s->attn_teams;
+    if (k == "accept_top_k") return s->accept_top_k;
     if (k == "gemm_prefill") return s->gemm_prefill;
     if (k == "persist") return s->persist;
     if (k == "prefill_rows") return s->prefill_rows;
@@ -522,6 +529,7 @@ static int build_program(kg_session* s, int which, const KgDyn* dyn, int max_row
         a.norm_w = s->w.final_norm; a.eps = sh.rms_eps;
         a.head_part = s->head_part; a.head_part_stride = s->head_part_stride;
         a.logits_stride = sh.vocab_size;
+        if (which == 0 && s->accept_top_k > 1) a.logits_out = s->vlogits;
         if (!add_lin(KG_PH_HEAD, OP_HEAD, a)) return 0;
     }
     if (kg_persist_max_blocks(sh.dtype, smem) < nblk) return 0;
@@ -579,9 +587,10 @@ static int enqueue_round(kg_session* s, int steps, hipStream_t st) {
             KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_verify, vrows, cur, s->h2, st));
             cur = s->h2;
         }
-        KG_TRY(run_head(s, s->dyn_verify, vrows, s->h2, 0, s->w.final_norm, nullptr, &nb, st));
+        KG_TRY(run_head(s, s->dyn_verify, vrows, s->h2, 0, s->w.final_norm, s->accept_top_k > 1 ? s->vlogits : nullptr, &nb, st));
     }
-    KG_TRY(kg_launch_accept(b, s->head_part, s->head_part_stride, nb, st));
+    if (s->accept_top_k > 1) KG_TRY(kg_launch_topk_rank(b, s->vlogits, sh.vocab_size, s->topk_rank, sh.dtype, st));
+    KG_TRY(kg_launch_accept(b, s->head_part, s->head_part_stride, nb, s->topk_rank, s->accept_top_k, st));
     return 0;
 }
 

@@ -228,9 +228,13 @@ class KangarooEngine:
 
     # ---- fused loops ---------------------------------------------------------------
     def generate(self, prompt_ids, max_new_tokens: int, mode: str = "kangaroo", steps: int = 6, threshold: float = 0.6,
-                 eos_token_id: int = 2, max_length: Optional[int] = None):
+                 eos_token_id: int = 2, max_length: Optional[int] = None, accept_top_k: int = 1):
         """Whole kangaroo_forward (mode='kangaroo') or plain greedy decoding (mode='vanilla')
-        on the device.  Returns (output_ids list, GenStats)."""
+        on the device.  accept_top_k > 1: top-k verification (a drafted token is kept while it is
+        among the k largest verify logits; evaluation/inference_kangaroo_MTBench.py:377-389) instead
+        of the greedy rule.  Returns (output_ids list, GenStats)."""
+        if mode == "kangaroo" and self.get_tuning("accept_top_k") != int(accept_top_k):
+            self.set_tuning(accept_top_k=int(accept_top_k))
         if isinstance(prompt_ids, torch.Tensor):
             prompt = prompt_ids.reshape(-1).to("cpu", torch.int32).contiguous()
         else:

@@ -52,6 +52,13 @@ def _import_reference():
     return ref_adapter, ref_forward
 
 
+def _import_reference_mtbench():
+    """evaluation/inference_kangaroo_MTBench.kangaroo_forward: the loop with the non-greedy
+    verification rules (call after _import_reference: same stubs; tqdm is real)."""
+    from evaluation.inference_kangaroo_MTBench import kangaroo_forward as ref_forward_mt
+    return ref_forward_mt
+
+
 class _Out:
     pass
 
@@ -172,7 +179,7 @@ def build_reference_model(ref_adapter, shape, base_sd, adapter_sd, exit_layer):
     return RefKangaroo(base, adapter, head.eval())
 
 
-def run_reference(ref_forward, model, ids, eos, max_new_tokens, exit_layer, steps, threshold):
+def run_reference(ref_forward, model, ids, eos, max_new_tokens, exit_layer, steps, threshold, extra=None):
     """Run the unmodified reference loop, recording per-round draft lengths, per-step
     confidences and logits through call-counting wrappers (no reference edits)."""
     rec = {"adapter_calls": 0, "draft_lengths": [], "head_rows": [], "verify_logits": [], "draft_logits": []}
@@ -205,7 +212,7 @@ def run_reference(ref_forward, model, ids, eos, max_new_tokens, exit_layer, step
     model.head_model.forward = head_wrap
     try:
         out = ref_forward(_Inputs(ids), model, _Tok(eos), max_new_tokens, EARLY_STOP_LAYER=exit_layer,
-                          SPECULATIVE_DECODING_STEPS=steps, threshold=threshold)
+                          SPECULATIVE_DECODING_STEPS=steps, threshold=threshold, **(extra or {}))
     finally:
         model.adapter_model.forward_early_stop = ad_orig
         model.base_model.forward_draft_or_large_model = base_orig
@@ -225,6 +232,9 @@ CASES = [
     ("tinymha_agree_h10_d02_L3", "tiny-mha", 3, 6, 0.6, dict(deep_scale=0.2, head_scale=10.0, adapter_o_zero=True, adapter_norm_from_base=True), 5, [8, 30], 64),
     ("tiny_thr0", "tiny", 2, 6, 0.0, dict(deep_scale=0.3, head_scale=8.0, adapter_o_zero=True, adapter_norm_from_base=True), 6, [10], 48),
     ("tiny_thr2", "tiny", 2, 6, 2.0, dict(deep_scale=0.3, head_scale=8.0, adapter_o_zero=True, adapter_norm_from_base=True), 7, [10], 48),
+    # top-k verification (inference_kangaroo_MTBench.py:377-389): the name carries the rule, main() reads k from it
+    ("tiny_topk2_h8_d05", "tiny", 2, 6, 0.6, dict(deep_scale=0.5, head_scale=8.0, adapter_o_zero=True, adapter_norm_from_base=True), 8, [9, 14], 64),
+    ("tinymha_topk3_h6_d08", "tiny-mha", 2, 6, 0.6, dict(deep_scale=0.8, head_scale=6.0, adapter_o_zero=True, adapter_norm_from_base=True), 9, [12], 64),
 ]
 
 
@@ -232,15 +242,22 @@ def main():
     from kangaroo_amd.config import get_shape
     from kangaroo_amd.weights import synth_state_dicts, Recipe
     ref_adapter, ref_forward = _import_reference()
+    ref_forward_mt = _import_reference_mtbench()
+    only = set(sys.argv[1:])
     outdir = os.path.join(REPO, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
     summary = {}
     for name, shape_name, L, steps, thr, rk, seed, plens, max_new in CASES:
+        if only and name not in only:
+            continue
+        top_k = int(name.split("_topk")[1].split("_")[0]) if "_topk" in name else 1
+        fwd = ref_forward_mt if top_k > 1 else ref_forward
+        extra = dict(do_sample="top_k", hyper_k=top_k, temperature=0.7) if top_k > 1 else None
         shape = get_shape(shape_name)
         base_sd, adapter_sd = synth_state_dicts(shape, L, seed=seed, dtype=torch.float16, recipe=Recipe(**rk))
         model = build_reference_model(ref_adapter, shape, base_sd, adapter_sd, L)
         blob = {"meta": json.dumps(dict(shape=shape_name, exit_layer=L, steps=steps, threshold=thr, recipe=rk,
-                                        seed=seed, max_new_tokens=max_new, eos=2, n_prompts=len(plens)))}
+                                        seed=seed, max_new_tokens=max_new, eos=2, n_prompts=len(plens), accept_top_k=top_k))}
         for k, v in base_sd.items():
             blob["base/" + k] = v.numpy()
         for k, v in adapter_sd.items():
@@ -249,7 +266,7 @@ def main():
         for pi, plen in enumerate(plens):
             g = torch.Generator().manual_seed(1000 * seed + pi)
             ids = torch.randint(3, shape.vocab_size, (1, plen), generator=g)
-            (out_ids, new_token, idx, accept), rec = run_reference(ref_forward, model, ids, 2, max_new, L, steps, thr)
+            (out_ids, new_token, idx, accept), rec = run_reference(fwd, model, ids, 2, max_new, L, steps, thr, extra)
             # losslessness against a plain greedy decode through the same reference layers
             blob[f"p{pi}/input_ids"] = ids.numpy()
             blob[f"p{pi}/output_ids"] = np.asarray(out_ids[0], dtype=np.int64)
@@ -266,9 +283,13 @@ def main():
         np.savez_compressed(os.path.join(outdir, name + ".npz"), **blob)
         summary[name] = accs
         print(name, accs)
-    # layer-level vectors straight from the reference classes
-    layer_vectors(ref_adapter, outdir)
-    with open(os.path.join(outdir, "SUMMARY.json"), "w") as f:
+    sfile = os.path.join(outdir, "SUMMARY.json")
+    if only and os.path.exists(sfile):          # regenerating some cases: keep the others' entries
+        with open(sfile) as f:
+            summary = {**json.load(f), **summary}
+    else:
+        layer_vectors(ref_adapter, outdir)      # layer-level vectors straight from the reference classes
+    with open(sfile, "w") as f:
         json.dump(summary, f)
 
 

@@ -293,9 +293,15 @@ class Trace:
 
 def kangaroo_forward(input_ids: torch.Tensor, model, eos_token_id: int, max_new_tokens: int,
                      max_length: int = 2048, EARLY_STOP_LAYER: int = 2, SPECULATIVE_DECODING_STEPS: int = 6,
-                     threshold: float = 0.6, trace: Optional[Trace] = None, keep_logits: bool = False):
+                     threshold: float = 0.6, trace: Optional[Trace] = None, keep_logits: bool = False,
+                     accept_top_k: int = 1):
     """evaluation/inference_kangaroo.py:15-129, statement for statement, with KV
     truncation expressed on the [1,Hkv,T,hd] tensors exactly as :108-119 does.
+
+    accept_top_k > 1 swaps the greedy test of :97 for the top-k membership test of
+    evaluation/inference_kangaroo_MTBench.py:377-389 (a drafted token is kept while it is among
+    the k largest verify logits of its row; the first one that is not is replaced by the row's
+    argmax).  accept_top_k == 1 is the greedy rule.
 
     Returns ([output_ids], new_token, idx, accept_length_list)."""
     context_tokens = input_ids
@@ -369,9 +375,14 @@ def kangaroo_forward(input_ids: torch.Tensor, model, eos_token_id: int, max_new_
                 trace.verify_logits.append(logits[0].clone())
 
         output_length = end_index - start_index                                                   # :95
+        if accept_top_k > 1:
+            output_topk_tokens = torch.topk(logits, k=accept_top_k, dim=-1).indices               # MTBench :379
         for i in range(output_length):                                                            # :96
-            if i == output_length - 1 or output_tokens[0, i] == eos_token_id or \
-                    output_tokens[0, i] != global_tokens[0, start_index + 1 + i]:                 # :97
+            if accept_top_k > 1:
+                rejected = global_tokens[0, start_index + 1 + i] not in output_topk_tokens[0, i, :]   # MTBench :384
+            else:
+                rejected = output_tokens[0, i] != global_tokens[0, start_index + 1 + i]           # :97
+            if i == output_length - 1 or output_tokens[0, i] == eos_token_id or rejected:
                 global_tokens[0, start_index + 1 + i] = output_tokens[0, i]                       # :98
                 start_index = start_index + 1 + i                                                 # :99
                 if output_tokens[0, i] == eos_token_id:                                           # :100

@@ -84,11 +84,25 @@ def test_fused_loop_matches_reference_golden(path):
     z, meta, base, adapter = load_case(path)
     shape = get_shape(meta["shape"])
     model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, meta["exit_layer"])
+    top_k = meta.get("accept_top_k", 1)          # > 1: top-k verification (inference_kangaroo_MTBench.py:377-389)
+    rule = dict(do_sample="top_k", hyper_k=top_k) if top_k > 1 else {}
     for pi in range(meta["n_prompts"]):
         ids = torch.from_numpy(z[f"p{pi}/input_ids"]).cuda()
         out, new_tok, idx, accept, st = kangaroo_forward(ids, model, meta["eos"], meta["max_new_tokens"], EARLY_STOP_LAYER=meta["exit_layer"],
-                                                         SPECULATIVE_DECODING_STEPS=meta["steps"], threshold=meta["threshold"], return_stats=True)
+                                                         SPECULATIVE_DECODING_STEPS=meta["steps"], threshold=meta["threshold"], return_stats=True, **rule)
         gold = z[f"p{pi}/output_ids"].tolist()
+        if top_k > 1:
+            # not lossless by design, and a divergence could also be a near-tie at the k-th logit:
+            # these fixtures are required to reproduce exactly
+            assert out[0] == gold
+            ref_accept, ref_draft = z[f"p{pi}/accept_length_list"].tolist(), z[f"p{pi}/draft_lengths"].tolist()
+            if accept != ref_accept or st.draft_lengths != ref_draft:
+                # same ids, different round boundaries: a draft confidence within 16-bit noise of the threshold
+                why = explain_round_divergence(accept, st.draft_lengths, ref_accept, ref_draft, z[f"p{pi}/p_max"], z[f"p{pi}/draft_logits"], meta["threshold"])
+                print(f"EXPLAINED {os.path.basename(path)} p{pi}: {why}")
+            else:
+                assert (new_tok, idx) == (int(z[f"p{pi}/new_token"]), int(z[f"p{pi}/idx"]))
+            continue
         if out[0] != gold:
             om = oracle_model(meta["shape"], base, adapter, meta["exit_layer"])
             at = explain_divergence(out[0], gold, ids.shape[1], om)
