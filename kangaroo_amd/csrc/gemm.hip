@@ -7,15 +7,19 @@
 //
 // Same packed weight tiles as the decode kernels.  A wave owns one 16-row group of W and
 // walks all of K: per k-batch of 8 tiles it holds the 8 A fragments in registers (two
-// batches in flight) and multiplies them with four 16-row column blocks of X^T, which the
-// block stages in LDS batch by batch (64 rows x 256 k, double-buffered; RMSNorm's gamma is
-// applied while staging and the row factor afterwards, as in the decode kernels).  The
-// accumulators go through the decode kernels' own epilogue code, so rounding is identical.
+// batches in flight) and multiplies them with four 16-row column blocks of X^T from LDS.  X^T is
+// staged batch by batch (64 rows x 128 k, double-buffered, XOR-swizzled) by two extra LOADER waves
+// of the block; RMSNorm's gamma can be applied while staging and the row factor afterwards, as in
+// the decode kernels.  The split matters because a wave's loads retire in order: a wave that both
+// streams weights several batches ahead and waits for the next X batch drains its own weight
+// queue at every step (measured: half of a block's time went into that wait).  The accumulators
+// go through the decode kernels' own epilogue code, so rounding is identical.
 #include "kg_linear_body.h"
 
 #ifndef GEMM_KB
 #define GEMM_KB 4                   // weight tiles (32 k each) per k-batch
 #endif
+#define GEMM_LW 2                   // loader waves per block (stage X; the other GEMM_NW waves stream weights and run the MFMAs)
 #define GEMM_XROW (GEMM_KB * 64)    // bytes of one X row of a k-batch in LDS: exactly one 256-byte bank row
 // 16-byte piece p of row `row` sits at piece slot p ^ (row & 15): the 16 lanes ds_read_b128 serves
 // together read 16 different rows at (nearly) one column, which the XOR spreads over all 16 slots.
@@ -25,11 +29,12 @@ static_assert(GEMM_KB == 4, "the LDS swizzle assumes 256-byte rows");
 // GEMM_NW = waves (= weight row groups) per block: 4 shares one staged X batch among more
 // row groups; 2 keeps 128 blocks for the 4096-row projections.
 template <int DT, int PRO, int EPI, int GEMM_NW>
-__global__ void __launch_bounds__(GEMM_NW * 64) kg_gemm_kernel(const KgLinArgs a) {
-    constexpr int GEMM_STAGE = KG_GEMM_ROWS * (GEMM_KB * 4) / (GEMM_NW * 64);
+__global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const KgLinArgs a) {
+    constexpr int GEMM_STAGE = KG_GEMM_ROWS * (GEMM_KB * 4) / (GEMM_LW * 64);    // 16-byte pieces of a batch each loader thread stages
     constexpr int PPR = GEMM_KB * 4;                                   // 16-byte pieces per X row of a batch
-    constexpr int RPJ = GEMM_NW * 64 / PPR;                            // rows one staging step covers    // 16-byte pieces of a batch each thread stages
+    constexpr int RPJ = GEMM_LW * 64 / PPR;                            // rows one staging step covers
     typedef KgT<DT> T;
+    KG_TSTAMP(a, 0);
     const KgDyn* dyn = a.dyn;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, r = lane & 15;
@@ -37,7 +42,9 @@ __global__ void __launch_bounds__(GEMM_NW * 64) kg_gemm_kernel(const KgLinArgs a
     const int M = dyn->n_rows;
     if (dyn->active == 0) return;
     const int G = (a.N + 15) >> 4, KT = a.K >> 5, NB = (KT + GEMM_KB - 1) / GEMM_KB;
-    const int rg = blockIdx.x * GEMM_NW + wave;        // >= G in the last block: loads out of range, nothing stored
+    const bool loader = wave >= GEMM_NW;               // wave-uniform role
+    const int ltid = tid - GEMM_NW * 64;               // loader thread index (negative in compute waves)
+    const int rg = blockIdx.x * GEMM_NW + (loader ? 0 : wave);     // >= G in the last block: loads out of range, nothing stored
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs0 = smem;
     char* xs1 = smem + KG_GEMM_ROWS * GEMM_XROW;
@@ -61,7 +68,7 @@ __global__ void __launch_bounds__(GEMM_NW * 64) kg_gemm_kernel(const KgLinArgs a
         }
     };
     // staging: piece q = tid + nthreads * j covers row q / PPR, 16-byte column q % PPR of the batch
-    const int scol = tid % PPR, srow0 = tid / PPR;
+    const int scol = (ltid & (PPR - 1)), srow0 = (ltid >= 0 ? ltid : 0) / PPR;
     auto stage_load = [&](kg_u4 (&sx)[GEMM_STAGE], kg_u4& gw, int step) {
         const int b = kbatch(step);
         const bool kok = (GEMM_KB * b + (scol >> 2)) < KT;
@@ -114,43 +121,79 @@ __global__ void __launch_bounds__(GEMM_NW * 64) kg_gemm_kernel(const KgLinArgs a
             for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) acc[cb] = T::mfma(wv[u], x[u][cb], acc[cb]);
     };
 
-    // Software pipeline.  Weights: ring of D register batches, all but one in flight (a CU runs
-    // one or two blocks here, so the bytes in flight per wave have to cover the HBM latency on
-    // their own).  X: batch b sits in LDS buffer b & 1; batches b+1 .. b+XS are on their way in XS
-    // register sets (an L2 round trip is several step times), and the set holding X(b+1) is
-    // stored to LDS behind the MFMAs of step b.
-    constexpr int D = (GEMM_NW == 4) ? 6 : 8;
-    constexpr int XS = (GEMM_NW == 4) ? 3 : 2;
-    constexpr int U = (D % XS == 0) ? D : D * XS;       // steps per unrolled round: a multiple of D, XS and 2
+    // Software pipeline, one block barrier per k-batch.  Compute waves: ring of D register batches of
+    // weights, all but one in flight.  Loader waves: X(b) sits in LDS buffer b & 1; X(b+1) .. X(b+XS)
+    // are on their way in XS register sets; during step b the set holding X(b+1) goes to the other
+    // LDS buffer and is re-requested for X(b+1+XS).
+    constexpr int D = 4;
+    constexpr int XS = 4;
+    constexpr int U = 4;                                // steps per unrolled round: a multiple of D, XS and 2
     static_assert(U % D == 0 && U % XS == 0 && U % 2 == 0, "ring indices must repeat every unrolled round");
-    kg_u4 w[D][GEMM_KB];
-    kg_u4 sx[XS][GEMM_STAGE], gw[XS];
+#ifdef KG_LIN_TLOG
+    unsigned long long tl_issue = 0, tl_compute = 0, tl_store = 0, tl_barrier = 0;
+#define GEMM_TL(var, t0_) do { const unsigned long long t1_ = wall_clock64(); var += t1_ - t0_; t0_ = t1_; } while (0)
+#else
+#define GEMM_TL(var, t0_) do { } while (0)
+#endif
+    if (loader) {
+        kg_u4 sx[XS][GEMM_STAGE], gw[XS];
 #pragma unroll
-    for (int i = 0; i < XS; ++i) gw[i] = kg_u4{0u, 0u, 0u, 0u};
-    stage_load(sx[0], gw[0], 0);
-    issue_w(w[0], 0);
+        for (int i = 0; i < XS; ++i) gw[i] = kg_u4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int i = 1; i < XS; ++i) stage_load(sx[i], gw[i], i);
-#pragma unroll
-    for (int i = 1; i < D - 1; ++i) issue_w(w[i], i);
-    stage_store(sx[0], gw[0], xs0);
-    stage_load(sx[0], gw[0], XS);
-    __syncthreads();
-    // step b: weights W(b) in wc; wr is the ring slot freed by step b-1; (sxe, gwe) holds X(b+1)
-    auto step = [&](kg_u4 (&wc)[GEMM_KB], kg_u4 (&wr)[GEMM_KB], kg_u4 (&sxe)[GEMM_STAGE], kg_u4& gwe, int b) {
-        issue_w(wr, b + D - 1);
-        compute(wc, (b & 1) ? xs1 : xs0);
-        stage_store(sxe, gwe, (b & 1) ? xs0 : xs1);
-        stage_load(sxe, gwe, b + 1 + XS);
+        for (int i = 0; i < XS; ++i) stage_load(sx[i], gw[i], i);
+        stage_store(sx[0], gw[0], xs0);
+        stage_load(sx[0], gw[0], XS);
         __syncthreads();
-    };
-    for (int b = 0; b < NB; b += U) {      // batches past the last one: zeros in, zeros added
+        for (int b = 0; b < NB; b += U) {
 #pragma unroll
-        for (int i = 0; i < U; ++i) step(w[i % D], w[(i + D - 1) % D], sx[(i + 1) % XS], gw[(i + 1) % XS], b + i);
+            for (int i = 0; i < U; ++i) {
+                const int bb = b + i;
+#ifdef KG_LIN_TLOG
+                unsigned long long tl0 = wall_clock64();
+#endif
+                stage_store(sx[(i + 1) % XS], gw[(i + 1) % XS], (bb & 1) ? xs0 : xs1);      // X(bb + 1)
+                GEMM_TL(tl_store, tl0);
+                stage_load(sx[(i + 1) % XS], gw[(i + 1) % XS], bb + 1 + XS);
+                GEMM_TL(tl_issue, tl0);
+                __syncthreads();
+                GEMM_TL(tl_barrier, tl0);
+            }
+        }
+    } else {
+        kg_u4 w[D][GEMM_KB];
+#pragma unroll
+        for (int i = 0; i < D - 1; ++i) issue_w(w[i], i);
+        __syncthreads();
+        KG_TSTAMP(a, 1);
+        for (int b = 0; b < NB; b += U) {      // batches past the last one: zeros in, zeros added
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int bb = b + i;
+#ifdef KG_LIN_TLOG
+                unsigned long long tl0 = wall_clock64();
+#endif
+                issue_w(w[(i + D - 1) % D], bb + D - 1);
+                GEMM_TL(tl_issue, tl0);
+                compute(w[i % D], (bb & 1) ? xs1 : xs0);
+                GEMM_TL(tl_compute, tl0);
+                __syncthreads();
+                GEMM_TL(tl_barrier, tl0);
+            }
+        }
     }
 
+#ifdef KG_LIN_TLOG
+    if (threadIdx.x == 0) {
+        unsigned long long* tl = &kg_lin_tlog[((size_t)a.logits_stride * gridDim.x + blockIdx.x) * 8];
+        tl[2] = tl_issue; tl[3] = tl_compute; tl[5] = tl_barrier; tl[6] = wall_clock64();
+    }
+    if (threadIdx.x == GEMM_NW * 64) {      // first loader thread: its X wait + LDS store time goes to slot 4
+        unsigned long long* tl = &kg_lin_tlog[((size_t)a.logits_stride * gridDim.x + blockIdx.x) * 8];
+        tl[4] = tl_store;
+    }
+#endif
     // ---- row factors of the deferred RMSNorm ----
-    if (PRO == PRO_RMSNORM) {
+    if (PRO == PRO_RMSNORM && loader) {
 #pragma unroll
         for (int j = 0; j < GEMM_STAGE; ++j) {
             float t = ss[j];
@@ -160,8 +203,8 @@ __global__ void __launch_bounds__(GEMM_NW * 64) kg_gemm_kernel(const KgLinArgs a
         }
     }
     // ---- epilogue inputs through LDS (the X buffers are free now), laid out as the decode epilogues expect ----
-    char* side = (EPI == EPI_RESID) ? xs0 + (size_t)wave * KG_GEMM_ROWS * 32 : xs0;
-    if (EPI == EPI_RESID) {
+    char* side = (EPI == EPI_RESID) ? xs0 + (size_t)(loader ? 0 : wave) * KG_GEMM_ROWS * 32 : xs0;
+    if (EPI == EPI_RESID && !loader) {
         const unsigned short* res = (const unsigned short*)a.resid;
         for (int e = lane; e < M * 16; e += 64) {
             const int m = e >> 4, n = rg * 16 + (e & 15);
@@ -169,14 +212,14 @@ __global__ void __launch_bounds__(GEMM_NW * 64) kg_gemm_kernel(const KgLinArgs a
         }
     } else if (EPI == EPI_ROPE_KV) {
         const int half = a.head_dim >> 1;
-        for (int i = tid; i < M * a.head_dim; i += GEMM_NW * 64) {
+        for (int i = tid; i < M * a.head_dim; i += (GEMM_NW + GEMM_LW) * 64) {
             const int m = i / a.head_dim, jj = i - m * a.head_dim;
             const size_t p = (size_t)(pos0 + m) * half;
             ((float*)side)[i] = (jj < half) ? a.rope_cos[p + jj] : a.rope_sin[p + jj - half];
         }
     }
     __syncthreads();
-    if (rg >= G) return;
+    if (loader || rg >= G) { KG_TSTAMP(a, 7); return; }
     HeadRun run; run.mx = -INFINITY; run.sum = 0.f; run.idx = 0;
 #pragma unroll
     for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) {
@@ -188,6 +231,7 @@ __global__ void __launch_bounds__(GEMM_NW * 64) kg_gemm_kernel(const KgLinArgs a
             epilogue_pair<DT, EPI, false>(a, rg * 16 + 4 * g + 2, m, pos0 + m, acc[cb][2] * rstd, acc[cb][3] * rstd, run, side, 0, M);
         }
     }
+    KG_TSTAMP(a, 7);
 }
 
 static int g_gemm_ncu = 256;
@@ -196,7 +240,7 @@ static size_t gemm_smem() { return (size_t)2 * KG_GEMM_ROWS * GEMM_XROW + KG_GEM
 template <int DT, int PRO, int NW>
 static int launch_epi(const KgLinArgs& a, int epi, hipStream_t st) {
     const int G = (a.N + 15) / 16;
-    const dim3 grid((G + NW - 1) / NW), block(NW * 64);
+    const dim3 grid((G + NW - 1) / NW), block((NW + GEMM_LW) * 64);
     const size_t smem = gemm_smem();
     switch (epi) {
     case EPI_STORE: hipLaunchKernelGGL((kg_gemm_kernel<DT, PRO, EPI_STORE, NW>), grid, block, smem, st, a); break;

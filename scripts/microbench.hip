@@ -2,7 +2,8 @@
 // Build: make -C kangaroo_amd/csrc microbench     Run: kangaroo_amd/csrc/microbench [what]
 #define KG_LIN_TLOG
 #include "../kangaroo_amd/csrc/kg_linear_body.h"
-__device__ unsigned long long kg_lin_tlog[64 * 256 * 8];
+__device__ unsigned long long kg_lin_tlog[64 * 1024 * 8];
+#include "../kangaroo_amd/csrc/gemm.hip"       // the prefill GEMM kernels with their timeline stamps compiled in
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -208,6 +209,47 @@ int main(int argc, char** argv) {
                 CK(hipGraphExecDestroy(ge));
             }
         }
+    }
+    if (what == "gemm_timeline") {
+        // 16 back-to-back 64-row GEMM passes (gate/up shape, then down shape): per block, the time spent
+        // in each part of a pipeline step, summed over the steps
+        kg_gemm_init();
+        KgDyn* dyn64; CK(hipMalloc(&dyn64, sizeof(KgDyn)));
+        CK(kg_launch_set_dyn(dyn64, 1, 64, 0, st) == 0 ? hipSuccess : hipErrorUnknown);
+        char* x64; CK(hipMalloc(&x64, (size_t)64 * 16384 * 2)); CK(hipMemset(x64, 0, (size_t)64 * 16384 * 2));
+        char* out64; CK(hipMalloc(&out64, (size_t)64 * 32768 * 2));
+        struct { const char* name; int N, K, epi; } cfg[] = {{"gateup", 22016, 4096, EPI_SILU_MUL}, {"qkv-like store", 12288, 4096, EPI_STORE}, {"down", 4096, 11008, EPI_STORE}};
+        for (auto& c : cfg) {
+            const int nlaunch = 16;
+            const size_t bytes = (size_t)c.N * c.K * 2;
+            const int G = c.N / 16, nw_ = (G >= 512) ? 4 : 2, nb = (G + nw_ - 1) / nw_;
+            hipGraphExec_t ge = capture(st, [&]() {
+                size_t off = 0;
+                for (int i = 0; i < nlaunch; ++i) {
+                    if (off + bytes > pool_bytes) off = 0;
+                    KgLinArgs a; memset(&a, 0, sizeof(a));
+                    a.W = pool + off; a.N = c.N; a.K = c.K; a.dyn = dyn64; a.x = x64; a.x_stride = c.K;
+                    a.out = out64; a.out_stride = c.epi == EPI_SILU_MUL ? c.N / 2 : c.N; a.logits_stride = i;
+                    if (kg_launch_gemm(a, KG_F16, PRO_NONE, c.epi, st) != 0) printf("launch refused\n");
+                    off += bytes;
+                }
+            });
+            float ms = time_graph(st, ge, 2) / nlaunch;
+            std::vector<unsigned long long> t((size_t)nlaunch * nb * 8);
+            CK(hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(kg_lin_tlog), t.size() * 8));
+            double s_pro = 0, s_issue = 0, s_comp = 0, s_store = 0, s_bar = 0, s_epi = 0, s_tot = 0;
+            for (int i = 1; i < nlaunch; ++i)
+                for (int b = 0; b < nb; ++b) {
+                    const unsigned long long* s = &t[((size_t)i * nb + b) * 8];
+                    s_pro += (double)(s[1] - s[0]); s_issue += (double)s[2]; s_comp += (double)s[3]; s_store += (double)s[4]; s_bar += (double)s[5];
+                    s_epi += (double)(s[7] - s[6]); s_tot += (double)(s[7] - s[0]);
+                }
+            const double n = (double)(nlaunch - 1) * nb * 100.0;      // -> us per block
+            printf("gemm %-15s %.1f us per launch, %d blocks x %d waves; per block: total %.1f us = prologue %.1f + weight issue %.1f + LDS reads/MFMA %.1f + barrier %.1f + epilogue %.1f | loader wave: X wait + LDS store %.1f\n",
+                   c.name, ms * 1e3, nb, nw_, s_tot / n, s_pro / n, s_issue / n, s_comp / n, s_bar / n, s_epi / n, s_store / n);
+            CK(hipGraphExecDestroy(ge));
+        }
+        return 0;
     }
     if (what == "timeline") {
         // 32 back-to-back launches of a gate/up-sized MFMA pass (7 rows) in one graph; per block the
