@@ -244,6 +244,12 @@ int main(int argc, char** argv) {
                     s_pro += (double)(s[1] - s[0]); s_issue += (double)s[2]; s_comp += (double)s[3]; s_store += (double)s[4]; s_bar += (double)s[5];
                     s_epi += (double)(s[7] - s[6]); s_tot += (double)(s[7] - s[0]);
                 }
+            {   // how many blocks of one launch enter late (i.e. had to wait for a CU slot)
+                unsigned long long first = ~0ull; int late = 0;
+                for (int b = 0; b < nb; ++b) { const unsigned long long e0 = t[((size_t)5 * nb + b) * 8]; if (e0 < first) first = e0; }
+                for (int b = 0; b < nb; ++b) if (t[((size_t)5 * nb + b) * 8] > first + 1000) ++late;
+                printf("   blocks entering more than 10 us after the first: %d of %d\n", late, nb);
+            }
             const double n = (double)(nlaunch - 1) * nb * 100.0;      // -> us per block
             printf("gemm %-15s %.1f us per launch, %d blocks x %d waves; per block: total %.1f us = prologue %.1f + weight issue %.1f + LDS reads/MFMA %.1f + barrier %.1f + epilogue %.1f | loader wave: X wait + LDS store %.1f\n",
                    c.name, ms * 1e3, nb, nw_, s_tot / n, s_pro / n, s_issue / n, s_comp / n, s_bar / n, s_epi / n, s_store / n);
