@@ -171,6 +171,7 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     if (hipMemset(s->attn_counters, 0, 4 * (size_t)shape->num_heads * sizeof(unsigned)) != hipSuccess) { delete s; return fail(-2, "hipMemset failed"); }
     for (int op = 0; op < 5; ++op) { s->waves[0][op] = 8; s->bpc[0][op] = 2; s->waves[1][op] = 8; s->bpc[1][op] = 1; }
     s->waves[0][1] = 4; s->waves[0][3] = 4;      // o_proj, down_proj: one row group per block, 4 waves measured best
+    s->bpc[0][0] = 1;                            // qkv GEMV: an 8-wave block fills a CU, a second block per CU only runs after it (measured 18.6 vs 20.2 us)
     s->waves[1][3] = 2;                          // down_proj in the large-K MFMA mode
     s->v_transposed = (shape->head_dim >= 32 && buffers->t_max % 32 == 0) ? 1 : 0;
     s->attn_nsplit = 16;
