@@ -46,6 +46,14 @@ def round_bytes(shape, L, d):
     return (d + 1) * L * lay + d * (ad + hd) + (shape.num_hidden_layers - L) * lay + hd
 
 
+def round_kv_bytes(shape, L, d, T):
+    """Algorithmic KV-cache bytes of the same round at context length T: every pass over a layer
+    reads that layer's K and V rows [0, T) once (2 * Hkv * hd * 2 B per position) and appends its own."""
+    per_pos = 2 * shape.num_key_value_heads * shape.head_dim * 2
+    passes = (d + 1) * L + d + (shape.num_hidden_layers - L)        # shallow layers, adapter, deep layers
+    return passes * per_pos * T + ((d + 1) * L + d + (d + 1) * (shape.num_hidden_layers - L)) * per_pos
+
+
 def cpu_baseline(shape, L, base_sd_gpu, adapter_sd_gpu, steps, thr, budget_new=32, prompt_len=32):
     """The oracle (CPU restatement of the reference loop, fp32 math on the same fp16
     weights) timed on the host cores over one short prompt."""
@@ -163,7 +171,14 @@ def main():
     # ---- achieved bytes / roofline ----
     dec_ms = sum(s.decode_ms for s in stats)
     bytes_dec = sum(round_bytes(shape, L, d) for s in stats for d in s.draft_lengths)
+    kv_dec = 0
+    for p, s in zip(timed, stats):
+        T = p.input_ids.shape[1]
+        for d, acc in zip(s.draft_lengths, s.accept_lengths):
+            kv_dec += round_kv_bytes(shape, L, d, T)
+            T += acc
     path_gbs = bytes_dec / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
+    path_kv_gbs = (bytes_dec + kv_dec) / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
     rows = a.spec_steps + 1
     us, wbytes = eng.bench_op("gateup", rows, iters=4 * shape.num_hidden_layers)
     ach = wbytes / (us * 1e-6) / 1e9
@@ -197,6 +212,7 @@ def main():
         "decode_only_tokens_per_s_rank0": (new_tokens - len(stats)) / (dec_ms * 1e-3) if dec_ms > 0 else None,
         "vanilla_tokens_per_s_rank0": van_tps, "speedup_vs_vanilla": speedup, "lossless": lossless,
         "hbm_GBps_decode_loop_rank0": path_gbs, "hbm_frac_decode_loop": path_gbs / HBM_PEAK_GBS,
+        "hbm_GBps_decode_loop_with_kv_rank0": path_kv_gbs, "hbm_frac_decode_loop_with_kv": path_kv_gbs / HBM_PEAK_GBS,
         "roofline": roofline, "kernels": per_kernel,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -145,8 +145,17 @@ int kg_session_get(kg_session* s, const char* key);
  * k > 1: a drafted token is kept while it is among the k largest verify logits of its row,
  * evaluation/inference_kangaroo_MTBench.py:377-389).  Block counts never change results; wave counts set how K is split
  * inside a block and therefore the fp32 summation order.  Values must be >= 1.
- * kg_session_get reads the per-op keys and "persist" (0 / 1) back. */
+ * kg_session_get reads the per-op keys and "persist" (0 / 1) back.
+ * "bench_layers": kg_bench_op cycles through this many layers' weights (all by default; 1 measures
+ * the kernels on cache-warm weights). */
 int kg_session_set(kg_session* s, const char* key, int value);
+/* Real-valued settings: "accept_top_p" (0: off; p in (0, 1]: top-p verification, a drafted token is
+ * kept while it lies in the pooled nuclei of the round's verify rows,
+ * evaluation/inference_kangaroo_MTBench.py:356-374; takes precedence over "accept_top_k") and
+ * "temperature" (> 0; divides the verify logits before that rule's softmax, :358).
+ * kg_session_getf returns the value, or -1 for an unknown key. */
+int kg_session_setf(kg_session* s, const char* key, float value);
+float kg_session_getf(kg_session* s, const char* key);
 
 /* Device address of a named region of the workspace ("tokens": int32[t_max], "state":
  * int32 loop state, "hs_early": the exit layer's input rows kept by the last prefill

@@ -58,6 +58,8 @@ SYMBOLS = {
     "kg_session_destroy": (_I, [_VP]),
     "kg_session_set": (_I, [_VP, C.c_char_p, _I]),
     "kg_session_get": (_I, [_VP, C.c_char_p]),
+    "kg_session_setf": (_I, [_VP, C.c_char_p, C.c_float]),
+    "kg_session_getf": (C.c_float, [_VP, C.c_char_p]),
     "kg_session_ptr": (_VP, [_VP, C.c_char_p]),
     "kg_set_tokens": (_I, [_VP, C.POINTER(C.c_int32), _I, _I, _VP]),
     "kg_forward_layers": (_I, [_VP, _I, _I, _VP, _I, _I, _VP, _VP]),

@@ -244,8 +244,72 @@ __global__ void kg_topk_rank_kernel(KgLoopBufs b, const unsigned short* logits, 
     if (threadIdx.x == 0) rank[i] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
+
+// Top-p verification (evaluation/inference_kangaroo_MTBench.py:356-374).  Row r of the verify logits,
+// divided by the temperature and soft-maxed, is sorted by falling probability; its nucleus is every
+// token whose predecessors in that order carry a total probability <= p (the first token always).
+// member[r * KG_MAX_ROWS + j] = 1 when the token drafted for position s+1+j lies in row r's nucleus:
+// the reference tests a drafted token against the nuclei of ALL rows of the round pooled together
+// (masked_select flattens them, :365), so the accept kernel takes the OR over r.  One block per row;
+// equal probabilities are ordered by token id, as a stable descending sort orders them.
+template <int DT>
+__global__ void kg_topp_member_kernel(KgLoopBufs b, const unsigned short* logits, int vocab, float temperature, float top_p, int* member) {
+    typedef KgT<DT> T;
+    constexpr int MAXJ = KG_MAX_ROWS - 1;
+    __shared__ float s_red[4][MAXJ + 2];
+    const int* st = b.state;
+    if (st[KS_ALIVE] == 0) return;
+    const int s = st[KS_START], q = st[KS_END] - s;
+    const int r = blockIdx.x;
+    if (r >= q) return;
+    const int nj = q - 1;                                // drafted tokens of this round
+    const unsigned short* row = logits + (size_t)r * vocab;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mx = -INFINITY;
+    for (int v = tid; v < vocab; v += blockDim.x) mx = fmaxf(mx, T::to_f(row[v]) / temperature);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) s_red[wave][0] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0][0], s_red[1][0]), fmaxf(s_red[2][0], s_red[3][0]));
+    __syncthreads();
+    float lt[MAXJ]; int it[MAXJ]; float mass[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        it[j] = j < nj ? b.tokens[s + 1 + j] : 0;
+        lt[j] = T::to_f(row[it[j]]);
+        mass[j] = 0.f;
+    }
+    float z = 0.f;
+    for (int v = tid; v < vocab; v += blockDim.x) {
+        const float l = T::to_f(row[v]);
+        const float e = __expf(l / temperature - mx);
+        z += e;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) mass[j] += (l > lt[j] || (l == lt[j] && v < it[j])) ? e : 0.f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        z += __shfl_xor(z, o, 64);
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) mass[j] += __shfl_xor(mass[j], o, 64);
+    }
+    if (lane == 0) {
+        s_red[wave][MAXJ + 1] = z;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) s_red[wave][1 + j] = mass[j];
+    }
+    __syncthreads();
+    if (tid < nj) {
+        const float zz = s_red[0][MAXJ + 1] + s_red[1][MAXJ + 1] + s_red[2][MAXJ + 1] + s_red[3][MAXJ + 1];
+        const float m = s_red[0][1 + tid] + s_red[1][1 + tid] + s_red[2][1 + tid] + s_red[3][1 + tid];
+        member[r * KG_MAX_ROWS + tid] = (m == 0.f || m / zz <= top_p) ? 1 : 0;
+    }
+}
+
 // accept / reject, cache rollback by length (:91-119).  top_k == 1: the greedy rule of :97; top_k > 1:
-// a drafted token survives while rank[i] < top_k (kg_topk_rank_kernel).
+// a drafted token survives while rank[i] < top_k (kg_topk_rank_kernel); top_k == 0: while it lies in the
+// pooled top-p nuclei, rank + KG_MAX_ROWS holding kg_topp_member_kernel's table.
 __global__ void kg_accept_kernel(KgLoopBufs b, const float* head_part, int stride, int nblocks, const int* rank, int top_k) {
     __shared__ float s_mx[8], s_sum[8]; __shared__ int s_idx[8];
     __shared__ int s_tok[KG_MAX_ROWS];
@@ -270,7 +334,16 @@ __global__ void kg_accept_kernel(KgLoopBufs b, const float* head_part, int strid
         int snew = s, stop = 0;
         for (int i = 0; i < q; ++i) {
             const int o = s_tok[i];
-            const bool rejected = (i == q - 1) ? true : (top_k > 1 ? rank[i] >= top_k : o != b.tokens[s + 1 + i]);
+            bool rejected = true;
+            if (i < q - 1) {
+                if (top_k > 1) rejected = rank[i] >= top_k;
+                else if (top_k == 1) rejected = o != b.tokens[s + 1 + i];
+                else {
+                    int in = 0;
+                    for (int r = 0; r < q; ++r) in |= rank[KG_MAX_ROWS + r * KG_MAX_ROWS + i];
+                    rejected = in == 0;
+                }
+            }
             if (i == q - 1 || o == eos || rejected) {                                 // :97
                 b.tokens[s + 1 + i] = o;                                              // :98
                 snew = s + 1 + i;                                                     // :99
@@ -322,6 +395,11 @@ int kg_launch_step_mid(const KgLoopBufs& b, int step, hipStream_t st) { KG_L1(kg
 int kg_launch_step_end(const KgLoopBufs& b, int step, const float* head_part, int nblocks, hipStream_t st) { KG_L1(kg_step_end_kernel, b, step, head_part, nblocks); }
 int kg_launch_verify_begin(const KgLoopBufs& b, hipStream_t st) { KG_L1(kg_verify_begin_kernel, b); }
 int kg_launch_accept(const KgLoopBufs& b, const float* head_part, int stride, int nblocks, const int* rank, int top_k, hipStream_t st) { KG_L1(kg_accept_kernel, b, head_part, stride, nblocks, rank, top_k); }
+int kg_launch_topp_member(const KgLoopBufs& b, const void* logits, int vocab, float temperature, float top_p, int* member, int dtype, hipStream_t st) {
+    if (dtype == KG_F16) hipLaunchKernelGGL(kg_topp_member_kernel<KG_F16>, dim3(KG_MAX_ROWS), dim3(256), 0, st, b, (const unsigned short*)logits, vocab, temperature, top_p, member);
+    else hipLaunchKernelGGL(kg_topp_member_kernel<KG_BF16>, dim3(KG_MAX_ROWS), dim3(256), 0, st, b, (const unsigned short*)logits, vocab, temperature, top_p, member);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 int kg_launch_topk_rank(const KgLoopBufs& b, const void* logits, int vocab, int* rank, int dtype, hipStream_t st) {
     if (dtype == KG_F16) hipLaunchKernelGGL(kg_topk_rank_kernel<KG_F16>, dim3(KG_MAX_ROWS), dim3(256), 0, st, b, (const unsigned short*)logits, vocab, rank);
     else hipLaunchKernelGGL(kg_topk_rank_kernel<KG_BF16>, dim3(KG_MAX_ROWS), dim3(256), 0, st, b, (const unsigned short*)logits, vocab, rank);

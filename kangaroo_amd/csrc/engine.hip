@@ -50,6 +50,7 @@ struct kg_session {
     int* head_tok; float* head_pmax;
     char* vlogits; int* topk_rank;     // verify logits rows and rank of each drafted token (top-k verification)
     int accept_top_k;                  // 1: greedy acceptance
+    float accept_top_p, temperature;   // accept_top_p > 0: top-p verification on logits / temperature
     int head_part_stride;
     int prefill_rows;
     // tuning
@@ -65,6 +66,7 @@ struct kg_session {
     char* rot; size_t rot_layer;       // per-layer activation buffers of the persistent passes
     char *pf_h, *pf_xn, *pf_xq, *pf_ao, *pf_act;   // activations of a prefill pass (KG_GEMM_ROWS rows)
     int gemm_prefill;                  // 1: prompts go through the 64-row GEMM passes
+    int bench_layers;                  // kg_bench_op cycles through this many layers' weights (1: cache-warm)
     unsigned long long* tlog;          // phase timeline of the last persistent launch (KG_PERSIST_TLOG=1), else null
     std::vector<int> prog_kinds[3];
     // graphs
@@ -114,7 +116,7 @@ static void carve(kg_session* s, Carver& c, const kg_shape* sh, int t_max) {
     int* head_tok = c.take<int>(R);
     float* head_pmax = c.take<float>(R);
     char* vlogits = c.take<char>(R * (size_t)sh->vocab_size * e);
-    int* topk_rank = c.take<int>(R);
+    int* topk_rank = c.take<int>(R + R * R);      // ranks, then the top-p membership table
     const int prog_cap = 5 * sh->num_layers + 2;
     KgPhase* prog0 = c.take<KgPhase>(prog_cap);
     KgPhase* prog1 = c.take<KgPhase>(prog_cap);
@@ -176,7 +178,9 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     s->v_transposed = (shape->head_dim >= 32 && buffers->t_max % 32 == 0) ? 1 : 0;
     s->attn_nsplit = 16;
     s->accept_top_k = 1;
+    s->accept_top_p = 0.f; s->temperature = 1.f;
     s->gemm_prefill = s->v_transposed;           // the 64-row passes need the MFMA attention kernel
+    s->bench_layers = s->sh.num_layers;
     s->attn_teams = 1;
     s->attn_blocks = 16;                         // one chunk per block: long contexts need many CUs pulling K/V (one CU sustains only ~60 GB/s)
     s->round_graph = nullptr; s->round_graph_steps = -1; s->vanilla_graph = nullptr;
@@ -220,6 +224,7 @@ extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
     bool done = false;
     if (k == "attn_nsplit") { if (value > 32) return fail(-1, "nsplit <= 32"); s->attn_nsplit = value; done = true; }
     if (k == "gemm_prefill") { s->gemm_prefill = (value >= 2 && s->v_transposed) ? 1 : 0; done = true; }   // 1: off, 2: on
+    if (k == "bench_layers") { s->bench_layers = value < s->sh.num_layers ? value : s->sh.num_layers; done = true; }
     if (k == "accept_top_k") { if (value > s->sh.vocab_size) return fail(-1, "accept_top_k <= vocab_size"); s->accept_top_k = value; done = true; }
     if (k == "attn_teams") { if (value > 2) return fail(-1, "attn_teams is 1 or 2"); s->attn_teams = value; done = true; }
     if (k == "attn_blocks") { if (value > 32) return fail(-1, "attn_blocks <= 32"); s->attn_blocks = value; done = true; }
@@ -241,6 +246,25 @@ extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
     if (s->vanilla_graph) { hipGraphExecDestroy(s->vanilla_graph); s->vanilla_graph = nullptr; }
     s->prog_n[0] = s->prog_n[1] = s->prog_n[2] = 0;
     return 0;
+}
+
+extern "C" int kg_session_setf(kg_session* s, const char* key, float value) {
+    if (!s || !key) return fail(-1, "null argument");
+    std::string k(key);
+    if (k == "accept_top_p") { if (!(value >= 0.f && value <= 1.f)) return fail(-1, "accept_top_p in [0, 1]"); s->accept_top_p = value; }
+    else if (k == "temperature") { if (!(value > 0.f)) return fail(-1, "temperature > 0"); s->temperature = value; }
+    else return fail(-1, "unknown key");
+    if (s->round_graph) { hipGraphExecDestroy(s->round_graph); s->round_graph = nullptr; s->round_graph_steps = -1; }
+    s->prog_n[0] = s->prog_n[1] = s->prog_n[2] = 0;
+    return 0;
+}
+
+extern "C" float kg_session_getf(kg_session* s, const char* key) {
+    if (!s || !key) return -1.f;
+    std::string k(key);
+    if (k == "accept_top_p") return s->accept_top_p;
+    if (k == "temperature") return s->temperature;
+    return -1.f;
 }
 
 extern "C" int kg_session_get(kg_session* s, const char* key) {
@@ -530,7 +554,7 @@ static int build_program(kg_session* s, int which, const KgDyn* dyn, int max_row
         a.norm_w = s->w.final_norm; a.eps = sh.rms_eps;
         a.head_part = s->head_part; a.head_part_stride = s->head_part_stride;
         a.logits_stride = sh.vocab_size;
-        if (which == 0 && s->accept_top_k > 1) a.logits_out = s->vlogits;
+        if (which == 0 && (s->accept_top_k > 1 || s->accept_top_p > 0.f)) a.logits_out = s->vlogits;
         if (!add_lin(KG_PH_HEAD, OP_HEAD, a)) return 0;
     }
     if (kg_persist_max_blocks(sh.dtype, smem) < nblk) return 0;
@@ -588,10 +612,11 @@ static int enqueue_round(kg_session* s, int steps, hipStream_t st) {
             KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_verify, vrows, cur, s->h2, st));
             cur = s->h2;
         }
-        KG_TRY(run_head(s, s->dyn_verify, vrows, s->h2, 0, s->w.final_norm, s->accept_top_k > 1 ? s->vlogits : nullptr, &nb, st));
+        KG_TRY(run_head(s, s->dyn_verify, vrows, s->h2, 0, s->w.final_norm, (s->accept_top_k > 1 || s->accept_top_p > 0.f) ? s->vlogits : nullptr, &nb, st));
     }
-    if (s->accept_top_k > 1) KG_TRY(kg_launch_topk_rank(b, s->vlogits, sh.vocab_size, s->topk_rank, sh.dtype, st));
-    KG_TRY(kg_launch_accept(b, s->head_part, s->head_part_stride, nb, s->topk_rank, s->accept_top_k, st));
+    if (s->accept_top_p > 0.f) KG_TRY(kg_launch_topp_member(b, s->vlogits, sh.vocab_size, s->temperature, s->accept_top_p, s->topk_rank + KG_MAX_ROWS, sh.dtype, st));
+    else if (s->accept_top_k > 1) KG_TRY(kg_launch_topk_rank(b, s->vlogits, sh.vocab_size, s->topk_rank, sh.dtype, st));
+    KG_TRY(kg_launch_accept(b, s->head_part, s->head_part_stride, nb, s->topk_rank, s->accept_top_p > 0.f ? 0 : s->accept_top_k, st));
     return 0;
 }
 
@@ -852,7 +877,7 @@ extern "C" int kg_bench_op(kg_session* s, int op, int rows, int iters, float* us
     if (!s || !us_per_launch || op < 0 || op > 4 || rows < 1 || rows > KG_MAX_ROWS || iters < 1 || iters > 4096) return fail(-1, "bad argument");
     hipStream_t st = s->own_stream;
     const kg_shape& sh = s->sh;
-    const int d = sh.hidden_size, F = sh.intermediate_size, dt = sh.dtype, N = sh.num_layers;
+    const int d = sh.hidden_size, F = sh.intermediate_size, dt = sh.dtype, N = s->bench_layers;
     KG_TRY(kg_launch_set_dyn(s->dyn_call, 1, rows, 0, st));
     KG_CHECK_HIP(hipStreamSynchronize(st));
     hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;

@@ -93,6 +93,7 @@ int kg_launch_step_end(const KgLoopBufs& b, int step, const float* head_part, in
 int kg_launch_verify_begin(const KgLoopBufs& b, hipStream_t st);
 // rank / top_k: top-k verification (top_k == 1: greedy, rank unused)
 int kg_launch_accept(const KgLoopBufs& b, const float* head_part, int stride, int nblocks, const int* rank, int top_k, hipStream_t st);
+int kg_launch_topp_member(const KgLoopBufs& b, const void* logits, int vocab, float temperature, float top_p, int* member, int dtype, hipStream_t st);
 int kg_launch_topk_rank(const KgLoopBufs& b, const void* logits, int vocab, int* rank, int dtype, hipStream_t st);
 int kg_launch_vanilla_begin(const KgLoopBufs& b, hipStream_t st);
 int kg_launch_vanilla_end(const KgLoopBufs& b, const float* head_part, int nblocks, hipStream_t st);

@@ -228,13 +228,22 @@ class KangarooEngine:
 
     # ---- fused loops ---------------------------------------------------------------
     def generate(self, prompt_ids, max_new_tokens: int, mode: str = "kangaroo", steps: int = 6, threshold: float = 0.6,
-                 eos_token_id: int = 2, max_length: Optional[int] = None, accept_top_k: int = 1):
+                 eos_token_id: int = 2, max_length: Optional[int] = None, accept_top_k: int = 1,
+                 accept_top_p: Optional[float] = None, temperature: float = 1.0):
         """Whole kangaroo_forward (mode='kangaroo') or plain greedy decoding (mode='vanilla')
         on the device.  accept_top_k > 1: top-k verification (a drafted token is kept while it is
         among the k largest verify logits; evaluation/inference_kangaroo_MTBench.py:377-389) instead
-        of the greedy rule.  Returns (output_ids list, GenStats)."""
-        if mode == "kangaroo" and self.get_tuning("accept_top_k") != int(accept_top_k):
-            self.set_tuning(accept_top_k=int(accept_top_k))
+        of the greedy rule.  accept_top_p: top-p verification on softmax(logits / temperature)
+        (a drafted token is kept while it lies in the pooled nuclei of the round's rows, :356-374).
+        Returns (output_ids list, GenStats)."""
+        if mode == "kangaroo":
+            if self.get_tuning("accept_top_k") != int(accept_top_k):
+                self.set_tuning(accept_top_k=int(accept_top_k))
+            want_p = C.c_float(float(accept_top_p) if accept_top_p else 0.0).value
+            if self.lib.kg_session_getf(self._handle, b"accept_top_p") != want_p or \
+                    (want_p > 0 and self.lib.kg_session_getf(self._handle, b"temperature") != C.c_float(temperature).value):
+                _lib.check(self.lib.kg_session_setf(self._handle, b"temperature", float(temperature)), "kg_session_setf(temperature)")
+                _lib.check(self.lib.kg_session_setf(self._handle, b"accept_top_p", want_p), "kg_session_setf(accept_top_p)")
         if isinstance(prompt_ids, torch.Tensor):
             prompt = prompt_ids.reshape(-1).to("cpu", torch.int32).contiguous()
         else:

