@@ -246,6 +246,41 @@ def test_top_p_one_keeps_every_draft():
     assert a == b
 
 
+def test_eos_stop_max_length_and_shortest_prompt_against_live_oracle():
+    """Loop exits of inference_kangaroo.py: an eos among the verified tokens ends the call with the eos
+    as last id (:97-100,123-124); max_length caps the budget (:43); a one-token prompt."""
+    z, meta, base, adapter = load_case(CASES[1])
+    L = meta["exit_layer"]
+    shape = get_shape(meta["shape"])
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, L)
+    om = lambda: oracle_model(meta["shape"], base, adapter, L)
+    ids = torch.from_numpy(z["p0/input_ids"])
+    T0 = ids.shape[1]
+    gold = z["p0/output_ids"].tolist()
+    checked = 0
+    # every generated token takes a turn as eos: accepted-draft, correction and bonus positions all occur
+    for k in range(T0, min(len(gold), T0 + 24)):
+        eos = gold[k]
+        ref = ko.kangaroo_forward(ids, om(), eos, 64, EARLY_STOP_LAYER=L)
+        out = kangaroo_forward(ids.cuda(), model, eos, 64, EARLY_STOP_LAYER=L)
+        assert ref[0][0][-1] == eos or len(ref[0][0]) > k + 1      # the reference stops only on a verify-side eos
+        assert out == ref, f"eos {eos} (position {k})"
+        checked += int(ref[0][0][-1] == eos)
+    assert checked >= 12
+    for max_length in (T0 + 9, T0 + 16, 48):
+        ref = ko.kangaroo_forward(ids, om(), -1, 64, max_length=max_length, EARLY_STOP_LAYER=L)
+        out = kangaroo_forward(ids.cuda(), model, -1, 64, max_length=max_length, EARLY_STOP_LAYER=L)
+        assert out == ref and len(out[0][0]) <= max_length
+    one = torch.tensor([[gold[3]]])
+    tr = ko.Trace()
+    ref = ko.kangaroo_forward(one, om(), -1, 24, EARLY_STOP_LAYER=L, trace=tr, keep_logits=True)
+    out = kangaroo_forward(one.cuda(), model, -1, 24, EARLY_STOP_LAYER=L, return_stats=True)
+    assert out[0] == ref[0]
+    if out[:4] != ref:
+        why = explain_round_divergence(out[3], out[4].draft_lengths, ref[3], tr.draft_lengths, tr.p_max, tr.draft_logits, 0.6)
+        print(f"EXPLAINED one-token prompt: {why}")
+
+
 def test_bf16_runs_and_is_lossless():
     shape = get_shape("small")
     base, adapter = synth_state_dicts(shape, 2, seed=21, dtype=torch.bfloat16, recipe=Recipe.agreeable(0.3, 8.0))
