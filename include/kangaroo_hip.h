@@ -139,7 +139,9 @@ int kg_session_get(kg_session* s, const char* key);
  * block working on different chunks at once): geometry only, results do not change;
  * "<mode>_waves" and "<mode>_blocks_per_cu" for all linear ops of a mode, or "<mode>.<op>.waves" /
  * "<mode>.<op>.blocks_per_cu" for one, with mode in {vec (1 row), mfma (2..16 rows)} and op in
- * {qkv, o, gateup, down, head}; "persist" (2: run the verify pass and the deep layers of plain
+ * {qkv, o, gateup, down, head}: with at most cap = CUs * blocks_per_cu blocks a block walks
+ * k = ceil(G / cap) of the op's G 16-row groups, and the launch uses ceil(G / k) blocks so that every
+ * block walks k or k - 1; "<mode>.<op>.blocks" sets the block count outright (blocks_per_cu resets it); "persist" (2: run the verify pass and the deep layers of plain
  * decoding as one persistent kernel with grid barriers, 1: one kernel per op, the default) and
  * "persist.<op>.waves"; "accept_top_k" (1: greedy acceptance, evaluation/inference_kangaroo.py:95-104;
  * k > 1: a drafted token is kept while it is among the k largest verify logits of its row,

@@ -56,6 +56,7 @@ struct kg_session {
     // tuning
     // launch geometry per (mode: 0 GEMV / 1 MFMA, op: qkv, o, gateup, down, head)
     int waves[2][5], bpc[2][5];
+    int nblk[2][5];                    // > 0: block count of the op, overriding blocks-per-CU
     int attn_nsplit, attn_blocks, attn_teams;
     int v_transposed;
     // persistent pass kernel: phase programs [0] verify pass, [1] deep layers of plain decoding
@@ -171,10 +172,13 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     carve(s, c, shape, buffers->t_max);
     s->prefill_rows = prefill_rows_for(shape);
     if (hipMemset(s->attn_counters, 0, 4 * (size_t)shape->num_heads * sizeof(unsigned)) != hipSuccess) { delete s; return fail(-2, "hipMemset failed"); }
-    for (int op = 0; op < 5; ++op) { s->waves[0][op] = 8; s->bpc[0][op] = 2; s->waves[1][op] = 8; s->bpc[1][op] = 1; }
+    // one block per CU in both modes: an 8-wave block fills a CU, a second one only queues behind it
+    for (int op = 0; op < 5; ++op) { s->waves[0][op] = 8; s->bpc[0][op] = 1; s->waves[1][op] = 8; s->bpc[1][op] = 1; s->nblk[0][op] = s->nblk[1][op] = 0; }
     s->waves[0][1] = 4; s->waves[0][3] = 4;      // o_proj, down_proj: one row group per block, 4 waves measured best
-    s->bpc[0][0] = 1;                            // qkv GEMV: an 8-wave block fills a CU, a second block per CU only runs after it (measured 18.6 vs 20.2 us)
     s->waves[1][3] = 2;                          // down_proj in the large-K MFMA mode
+    // o_proj, same kernel: the longer K, the fewer waves share a row group (measured at K = 4096 / 5120 / 6656:
+    // 8.6 us with 8 waves, 13.3 with 4 against 15.3 with 8, 17.1 with 2 against 20.4 with 8)
+    { const int Ko = shape->num_heads * shape->head_dim; s->waves[1][1] = Ko <= 4096 ? 8 : (Ko <= 5120 ? 4 : 2); }
     s->v_transposed = (shape->head_dim >= 32 && buffers->t_max % 32 == 0) ? 1 : 0;
     s->attn_nsplit = 16;
     s->accept_top_k = 1;
@@ -237,7 +241,8 @@ extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
         if (k == mname + "_blocks_per_cu") { for (int op = 0; op < 5; ++op) s->bpc[mode][op] = value; done = true; }
         for (int op = 0; op < 5 && !done; ++op) {
             if (k == mname + "." + kg_op_names[op] + ".waves") { if (value > 8) return fail(-1, "waves <= 8"); s->waves[mode][op] = value; done = true; }
-            if (k == mname + "." + kg_op_names[op] + ".blocks_per_cu") { s->bpc[mode][op] = value; done = true; }
+            if (k == mname + "." + kg_op_names[op] + ".blocks_per_cu") { s->bpc[mode][op] = value; s->nblk[mode][op] = 0; done = true; }
+            if (k == mname + "." + kg_op_names[op] + ".blocks") { s->nblk[mode][op] = value; done = true; }
         }
     }
     if (!done) return fail(-1, "unknown key");
@@ -304,8 +309,15 @@ extern "C" void* kg_session_ptr(kg_session* s, const char* name) {
 // ---------------------------------------------------------------------------------
 static int grid_for(const kg_session* s, int N, int max_rows, int op) {
     const int G = (N + 15) / 16;
-    const int nb = g_ncu * s->bpc[max_rows == 1 ? 0 : 1][op];
-    return nb < G ? nb : G;
+    const int mode = max_rows == 1 ? 0 : 1;
+    if (s->nblk[mode][op] > 0) return s->nblk[mode][op] < G ? s->nblk[mode][op] : G;
+    // Balanced: with at most cap blocks a block walks k = ceil(G / cap) row groups; ceil(G / k) blocks do
+    // that with every block within one group of k (1376 groups on 256 CUs: 230 blocks x 6 instead of
+    // 96 blocks x 6 and 160 x 5; 320 groups: 160 x 2 instead of 64 x 2 and 192 x 1).
+    const int cap = g_ncu * s->bpc[mode][op];
+    if (cap >= G) return G;
+    const int k = (G + cap - 1) / cap;
+    return (G + k - 1) / k;
 }
 static int waves_for(const kg_session* s, int max_rows, int op) { return s->waves[max_rows == 1 ? 0 : 1][op]; }
 
@@ -386,6 +398,9 @@ static KgLoopBufs loop_bufs(kg_session* s) {
     b.d = s->sh.hidden_size; b.elt = s->elt;
     return b;
 }
+
+// records the head phase of a persistent pass leaves: one per resident block that owns a row group
+static int persist_head_records(const kg_session* s) { const int G = (s->sh.vocab_size + 15) / 16; return g_ncu < G ? g_ncu : G; }
 
 static int build_program(kg_session* s, int which, const KgDyn* dyn, int max_rows, int l0, int l1, const void* x_in, void* hbuf, bool with_head);
 static int run_program(kg_session* s, int which, hipStream_t st);
@@ -605,7 +620,7 @@ static int enqueue_round(kg_session* s, int steps, hipStream_t st) {
     int nb = 0;
     if (s->prog_n[0] > 0) {
         KG_TRY(run_program(s, 0, st));
-        nb = grid_for(s, sh.vocab_size, vrows, OP_HEAD);     // both equal the CU count
+        nb = persist_head_records(s);
     } else {
         const void* cur = s->exited;
         for (int l = L; l < N; ++l) {
@@ -634,7 +649,7 @@ static int enqueue_vanilla(kg_session* s, hipStream_t st) {
         for (int l = 0; l < sh.exit_layer; ++l)
             KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_shallow, 1, s->h, s->h, st));
         KG_TRY(run_program(s, 1, st));
-        nb = grid_for(s, sh.vocab_size, 2, OP_HEAD);
+        nb = persist_head_records(s);
     } else {
         for (int l = 0; l < sh.num_layers; ++l)
             KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_shallow, l < sh.exit_layer ? 1 : 2, s->h, s->h, st));
