@@ -281,6 +281,40 @@ def test_eos_stop_max_length_and_shortest_prompt_against_live_oracle():
         print(f"EXPLAINED one-token prompt: {why}")
 
 
+def test_constructor_from_checkpoint_dirs_and_eval_harness(tmp_path):
+    """KangarooModel(base_dir, adapter_dir, args, EARLY_STOP_LAYER) reads the on-disk formats of
+    kangaroo/kangaroo_model.py:22-44 (sharded HF checkpoint + adapter directory); run_eval writes the
+    answer-file fields of evaluation/eval.py:232-233 and speed_report applies evaluation/speed.py's formulas."""
+    import types
+    from kangaroo_amd.harness import run_eval, speed_report, spec_bench_prompts
+    from kangaroo_amd.weights import save_synthetic_checkpoint
+    z, meta, base, adapter = load_case(CASES[1])
+    L = meta["exit_layer"]
+    shape = get_shape(meta["shape"])
+    save_synthetic_checkpoint(str(tmp_path / "base"), str(tmp_path / "adapter"), shape, base, adapter, n_shards=2)
+    model = KangarooModel(str(tmp_path / "base"), str(tmp_path / "adapter"), types.SimpleNamespace(dtype="float16"), EARLY_STOP_LAYER=L)
+    ids = torch.from_numpy(z["p0/input_ids"]).cuda()
+    out = kangaroo_forward(ids, model, meta["eos"], meta["max_new_tokens"], EARLY_STOP_LAYER=L, SPECULATIVE_DECODING_STEPS=meta["steps"], threshold=meta["threshold"])
+    assert out[0][0] == z["p0/output_ids"].tolist()
+    with pytest.raises(ValueError):
+        KangarooModel(str(tmp_path / "base"), str(tmp_path / "adapter"), types.SimpleNamespace(dtype="float32"), EARLY_STOP_LAYER=L)
+    # harness: kangaroo and vanilla over the same prompts
+    prompts = [p for p in spec_bench_prompts(shape.vocab_size, 12) if p.input_ids.shape[1] <= 200][:4]
+    fk = lambda ids, m, eos, n, **kw: kangaroo_forward(ids, m, eos, n, EARLY_STOP_LAYER=L, **kw)
+    fv = lambda ids, m, eos, n, **kw: vanilla_forward(ids, m, eos, n)
+    af = tmp_path / "answers.jsonl"
+    recs = run_eval(model, fk, prompts, 48, -1, answer_file=str(af), keep_ids=True)
+    base_recs = run_eval(model, fv, prompts, 48, -1, keep_ids=True)
+    for r, b in zip(recs, base_recs):
+        n = min(len(r.output_ids), len(b.output_ids))
+        assert r.output_ids[:n] == b.output_ids[:n]
+        assert sum(r.accept_lengths) == r.new_tokens and r.idxs == len(r.accept_lengths) - 1
+    rep = speed_report(recs, base_recs)
+    assert rep["speedup"] > 0 and 1.0 <= rep["mean_accept"] <= meta["steps"] + 1
+    lines = [json.loads(l) for l in open(af)]
+    assert len(lines) == len(prompts) and set(lines[0]["choices"][0]) >= {"new_tokens", "wall_time", "idxs", "accept_lengths"}
+
+
 def test_bf16_runs_and_is_lossless():
     shape = get_shape("small")
     base, adapter = synth_state_dicts(shape, 2, seed=21, dtype=torch.bfloat16, recipe=Recipe.agreeable(0.3, 8.0))
