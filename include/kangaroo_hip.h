@@ -87,20 +87,20 @@ const char* kg_last_error(void);
 
 /* ---- kernel-level entry points (unit parity tests call these) -------------------- */
 
-/* y = x W^T for n_rows <= 64 rows with the fused prologue/epilogue of the decode path.
+/* y = x W^T for n_rows <= 128 rows with the fused prologue/epilogue of the decode path.
  * Stands in for torch.nn.functional.linear as the reference's layers call it
  * (kangaroo/adapter.py:170-172,222,242; kangaroo/kangaroo_model.py:34).
  *   prologue 0: x used as is; 1: x = RMSNorm(x; norm_w, eps) (adapter.py:254-259)
  *   epilogue 0: out = y; 1: out = resid + y (adapter.py:304); 3: out = silu(y_gate) * y_up
  *            (adapter.py:242, rows interleaved as wgu)
- * n_rows == 1 runs the wave-reduced GEMV, 2..16 the MFMA decode kernel, 17..64 the prefill GEMM
+ * n_rows == 1 runs the wave-reduced GEMV, 2..16 the MFMA decode kernel, 17..128 the prefill GEMM
  * kernel (the base model's prompt pass, evaluation/inference_kangaroo.py:30; nblocks / nwaves unused). */
 int kg_linear(int dtype, const void* w_packed, int N, int K, const void* x, int n_rows,
               int prologue, const void* norm_w, float eps,
               int epilogue, const void* resid, void* out, int out_stride,
               void* scratch /* device, >= 256 B */, int nblocks, int nwaves, void* stream);
 
-/* Fused RMSNorm + QKV projection + RoPE + in-place KV append for n_rows (<= 64) rows at
+/* Fused RMSNorm + QKV projection + RoPE + in-place KV append for n_rows (<= 128) rows at
  * positions pos0.. (adapter.py:170-189 with the cache growing by torch.cat there).
  * K cache [Hkv][t_max][hd]; V cache [Hkv][t_max][hd] (v_transposed 0) or [Hkv][hd][t_max]
  * (v_transposed 1: the layout the MFMA attention kernel reads; head_dim 32/64/128 and
@@ -111,7 +111,7 @@ int kg_qkv_rope_append(int dtype, const void* wqkv_packed, int d, int n_heads, i
                        void* q_out, void* k_cache, void* v_cache, int t_max, int v_transposed,
                        void* scratch, int nblocks, int nwaves, void* stream);
 
-/* Causal attention of n_rows query rows (<= 16; <= 64 with v_transposed) at positions pos0..
+/* Causal attention of n_rows query rows (<= 16; <= 128 with v_transposed) at positions pos0..
  * over the cache rows [0, pos0 + n_rows) (adapter.py:191-221; the mask of :38-67 is the causal bound). */
 int kg_attention(int dtype, const void* q, int n_rows, int pos0, const void* k_cache, const void* v_cache,
                  int n_heads, int n_kv_heads, int head_dim, int t_max, int v_transposed, int nsplit,

@@ -66,7 +66,8 @@ struct kg_session {
     unsigned* bar;                     // [0..255] barrier counters, [256] abort flag
     char* rot; size_t rot_layer;       // per-layer activation buffers of the persistent passes
     char *pf_h, *pf_xn, *pf_xq, *pf_ao, *pf_act;   // activations of a prefill pass (KG_GEMM_ROWS rows)
-    int gemm_prefill;                  // 1: prompts go through the 64-row GEMM passes
+    float* pf_part;                    // K-range partial sums of the d-row prefill projections [4][KG_GEMM_ROWS][d]
+    int gemm_prefill;                  // 1: prompts go through the 128-row GEMM passes
     int bench_layers;                  // kg_bench_op cycles through this many layers' weights (1: cache-warm)
     unsigned long long* tlog;          // phase timeline of the last persistent launch (KG_PERSIST_TLOG=1), else null
     std::vector<int> prog_kinds[3];
@@ -111,7 +112,7 @@ static void carve(kg_session* s, Carver& c, const kg_shape* sh, int t_max) {
     const int nsplit_max = 32;
     float* part_o = c.take<float>((size_t)nsplit_max * KG_GEMM_ROWS * qd);
     float* part_ml = c.take<float>((size_t)nsplit_max * KG_GEMM_ROWS * sh->num_heads * 2);
-    unsigned* attn_counters = c.take<unsigned>(4 * (size_t)sh->num_heads);
+    unsigned* attn_counters = c.take<unsigned>((KG_GEMM_ROWS / 16) * (size_t)sh->num_heads);
     const int hp_stride = (sh->vocab_size + 15) / 16;
     float* head_part = c.take<float>((size_t)R * hp_stride * 4);
     int* head_tok = c.take<int>(R);
@@ -132,9 +133,10 @@ static void carve(kg_session* s, Carver& c, const kg_shape* sh, int t_max) {
     char* pf_xq = c.take<char>(PR * qd * e);
     char* pf_ao = c.take<char>(PR * qd * e);
     char* pf_act = c.take<char>(PR * F * e);
+    float* pf_part = c.take<float>(4 * PR * d);
     if (s) {
         s->prog_dev[0] = prog0; s->prog_dev[1] = prog1; s->prog_dev[2] = prog2; s->prog_cap = prog_cap; s->bar = bar; s->rot = rot; s->rot_layer = rot_layer;
-        s->pf_h = pf_h; s->pf_xn = pf_xn; s->pf_xq = pf_xq; s->pf_ao = pf_ao; s->pf_act = pf_act;
+        s->pf_h = pf_h; s->pf_xn = pf_xn; s->pf_xq = pf_xq; s->pf_ao = pf_ao; s->pf_act = pf_act; s->pf_part = pf_part;
         s->state = state; s->tokens = tokens;
         s->dyn_shallow = dyn; s->dyn_adapter = dyn + 1; s->dyn_verify = dyn + 2; s->dyn_call = dyn + 3;
         s->h = h; s->h2 = h2; s->xq = xq; s->attn_out = attn_out; s->act = act; s->exited = exited;
@@ -171,7 +173,7 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     Carver c{(char*)buffers->workspace, 0};
     carve(s, c, shape, buffers->t_max);
     s->prefill_rows = prefill_rows_for(shape);
-    if (hipMemset(s->attn_counters, 0, 4 * (size_t)shape->num_heads * sizeof(unsigned)) != hipSuccess) { delete s; return fail(-2, "hipMemset failed"); }
+    if (hipMemset(s->attn_counters, 0, (KG_GEMM_ROWS / 16) * (size_t)shape->num_heads * sizeof(unsigned)) != hipSuccess) { delete s; return fail(-2, "hipMemset failed"); }
     // one block per CU in both modes: an 8-wave block fills a CU, a second one only queues behind it
     for (int op = 0; op < 5; ++op) { s->waves[0][op] = 8; s->bpc[0][op] = 1; s->waves[1][op] = 8; s->bpc[1][op] = 1; s->nblk[0][op] = s->nblk[1][op] = 0; }
     s->waves[0][1] = 4; s->waves[0][3] = 4;      // o_proj, down_proj: one row group per block, 4 waves measured best
@@ -183,7 +185,7 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     s->attn_nsplit = 16;
     s->accept_top_k = 1;
     s->accept_top_p = 0.f; s->temperature = 1.f;
-    s->gemm_prefill = s->v_transposed;           // the 64-row passes need the MFMA attention kernel
+    s->gemm_prefill = s->v_transposed;           // the GEMM passes need the MFMA attention kernel
     s->bench_layers = s->sh.num_layers;
     s->attn_teams = 1;
     s->attn_blocks = 16;                         // one chunk per block: long contexts need many CUs pulling K/V (one CU sustains only ~60 GB/s)
@@ -682,7 +684,7 @@ static int run_layer_gemm(kg_session* s, const kg_layer_weights& lw, void* kc, v
                           const void* h_in, void* h_out, hipStream_t st) {
     const kg_shape& sh = s->sh;
     const int d = sh.hidden_size, F = sh.intermediate_size, dt = sh.dtype;
-    // The norms run as kernels of their own here (64 rows are normalised once instead of once per
+    // The norms run as kernels of their own here (the pass's rows are normalised once instead of once per
     // block that stages them), in the reference's order: normalise, round, scale (adapter.py:254-259).
     KG_TRY(kg_launch_rmsnorm(dyn, h_in, d, lw.norm1, sh.rms_eps, d, s->pf_xn, d, dt, st));
     {
@@ -703,7 +705,7 @@ static int run_layer_gemm(kg_session* s, const kg_layer_weights& lw, void* kc, v
     }
     {
         KgLinArgs a = lin_base(dyn, lw.wo, d, s->q_dim, s->pf_ao, s->q_dim);
-        a.out = h_out; a.out_stride = d; a.resid = h_in; a.resid_stride = d;
+        a.out = h_out; a.out_stride = d; a.resid = h_in; a.resid_stride = d; a.kpart = s->pf_part;
         KG_TRY(kg_launch_gemm(a, dt, PRO_NONE, EPI_RESID, st));
     }
     if (lw.wgu == nullptr) return 0;
@@ -715,13 +717,13 @@ static int run_layer_gemm(kg_session* s, const kg_layer_weights& lw, void* kc, v
     }
     {
         KgLinArgs a = lin_base(dyn, lw.wdown, d, F, s->pf_act, F);
-        a.out = h_out; a.out_stride = d; a.resid = h_out; a.resid_stride = d;
+        a.out = h_out; a.out_stride = d; a.resid = h_out; a.resid_stride = d; a.kpart = s->pf_part;
         KG_TRY(kg_launch_gemm(a, dt, PRO_NONE, EPI_RESID, st));
     }
     return 0;
 }
 
-// Prefill: all layers over the prompt in passes of C rows (64-row GEMM passes, or prefill_rows
+// Prefill: all layers over the prompt in passes of C rows (128-row GEMM passes, or prefill_rows
 // rows through the decode kernels); keeps the input of the exit layer for the adapter's cache
 // (inference_kangaroo.py:30-38).
 static int prefill(kg_session* s, int T0, bool with_adapter, hipStream_t st) {
@@ -957,7 +959,7 @@ extern "C" int kg_linear(int dtype, const void* w_packed, int N, int K, const vo
     g_err.clear();
     kg_init_once();
     if (!w_packed || !x || !out || !scratch) return fail(-1, "null argument");
-    if (n_rows < 1 || n_rows > KG_GEMM_ROWS) return fail(-1, "n_rows must be in [1, 64]");
+    if (n_rows < 1 || n_rows > KG_GEMM_ROWS) return fail(-1, "n_rows must be in [1, 128]");
     if (epilogue != EPI_STORE && epilogue != EPI_RESID && epilogue != EPI_SILU_MUL) return fail(-1, "epilogue must be 0, 1 or 3");
     if (prologue == PRO_RMSNORM && !norm_w) return fail(-1, "norm_w required");
     if (epilogue == EPI_RESID && !resid) return fail(-1, "resid required");
@@ -996,7 +998,7 @@ extern "C" int kg_qkv_rope_append(int dtype, const void* wqkv_packed, int d, int
 }
 
 extern "C" size_t kg_attention_scratch_bytes(int n_heads, int head_dim, int nsplit) {
-    return 256 + (size_t)nsplit * KG_GEMM_ROWS * n_heads * (head_dim + 2) * sizeof(float) + 256 + 4 * (size_t)n_heads * sizeof(unsigned);
+    return 256 + (size_t)nsplit * KG_GEMM_ROWS * n_heads * (head_dim + 2) * sizeof(float) + 256 + (KG_GEMM_ROWS / 16) * (size_t)n_heads * sizeof(unsigned);
 }
 
 extern "C" int kg_attention(int dtype, const void* q, int n_rows, int pos0, const void* k_cache, const void* v_cache,
@@ -1016,7 +1018,7 @@ extern "C" int kg_attention(int dtype, const void* q, int n_rows, int pos0, cons
     a.part_o = (float*)((char*)scratch + 256);
     a.part_ml = a.part_o + (size_t)nsplit * KG_GEMM_ROWS * n_heads * head_dim;
     a.counters = (unsigned*)(((uintptr_t)(a.part_ml + (size_t)nsplit * KG_GEMM_ROWS * n_heads * 2) + 255) & ~(uintptr_t)255);
-    KG_CHECK_HIP(hipMemsetAsync(a.counters, 0, 4 * (size_t)n_heads * sizeof(unsigned), st));
+    KG_CHECK_HIP(hipMemsetAsync(a.counters, 0, (KG_GEMM_ROWS / 16) * (size_t)n_heads * sizeof(unsigned), st));
     // partial buffers are indexed with max_rows = n_rows, within the KG_GEMM_ROWS-sized scratch
     a.out = out;
     int rc = kg_launch_attn(a, dtype, st);

@@ -1,25 +1,25 @@
-// Prefill linears (gfx950): Y[m][n] = sum_k X[m][k] W[n][k] for up to 64 rows (tokens) per pass.
+// Prefill linears (gfx950): Y[m][n] = sum_k X[m][k] W[n][k] for up to 128 rows (tokens) per pass.
 //
 // Decode streams every weight once per token; a prompt of T0 tokens run through the M<=16
-// decode kernels streams them T0/16 times.  Here a pass carries 64 rows, so the weights are
-// read T0/64 times, still far below the machine balance (64 flop per weight byte pair), i.e.
-// HBM-bound like everything else on this path.
+// decode kernels streams them T0/16 times.  Here a pass carries 128 rows, so the weights are
+// read T0/128 times.
 //
 // Same packed weight tiles as the decode kernels.  A wave owns one 16-row group of W and
-// walks all of K: per k-batch of 8 tiles it holds the 8 A fragments in registers (two
-// batches in flight) and multiplies them with four 16-row column blocks of X^T from LDS.  X^T is
-// staged batch by batch (64 rows x 128 k, double-buffered, XOR-swizzled) by two extra LOADER waves
+// walks all of K: per k-batch of 4 tiles it holds the A fragments in registers (a ring of four
+// batches, three in flight) and multiplies them with eight 16-row column blocks of X^T from LDS.  X^T is
+// staged batch by batch (128 rows x 128 k, double-buffered, XOR-swizzled) by four extra LOADER waves
 // of the block; RMSNorm's gamma can be applied while staging and the row factor afterwards, as in
 // the decode kernels.  The split matters because a wave's loads retire in order: a wave that both
 // streams weights several batches ahead and waits for the next X batch drains its own weight
 // queue at every step (measured: half of a block's time went into that wait).  The accumulators
 // go through the decode kernels' own epilogue code, so rounding is identical.
 #include "kg_linear_body.h"
+#include <cstdlib>
 
 #ifndef GEMM_KB
 #define GEMM_KB 4                   // weight tiles (32 k each) per k-batch
 #endif
-#define GEMM_LW 2                   // loader waves per block (stage X; the other GEMM_NW waves stream weights and run the MFMAs)
+#define GEMM_LW 4                   // loader waves per block (stage X; the other GEMM_NW waves stream weights and run the MFMAs)
 #define GEMM_XROW (GEMM_KB * 64)    // bytes of one X row of a k-batch in LDS: exactly one 256-byte bank row
 // 16-byte piece p of row `row` sits at piece slot p ^ (row & 15): the 16 lanes ds_read_b128 serves
 // together read 16 different rows at (nearly) one column, which the XOR spreads over all 16 slots.
@@ -56,8 +56,11 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
 
     // Blocks walk K in rotated order (block i starts at batch 5 i mod NB): otherwise every block
     // asks for the same X columns at the same moment and those few L2 channels serialise the grid.
-    const int bstart = (int)((blockIdx.x * 5u) % (unsigned)NB);
-    auto kbatch = [&](int step) { int b = step + bstart; if (b >= NB) b -= NB; return (step < NB) ? b : NB; };   // NB: out of range
+    // K ranges on grid.y (ksplit > 1): this block walks batches [kb0, kb0 + NBL)
+    const int KS = a.ksplit > 1 ? a.ksplit : 1;
+    const int kb0 = (int)(((long long)NB * blockIdx.y) / KS), NBL = (int)(((long long)NB * (blockIdx.y + 1)) / KS) - kb0;
+    const int bstart = NBL > 0 ? (int)((blockIdx.x * 5u) % (unsigned)NBL) : 0;
+    auto kbatch = [&](int step) { int b = step + bstart; if (b >= NBL) b -= NBL; return (step < NBL) ? kb0 + b : NB; };   // NB: out of range
     auto issue_w = [&](kg_u4 (&wv)[GEMM_KB], int step) {
         const int b = kbatch(step);
         const unsigned base = (unsigned)rg * (unsigned)KT * 1024u + (unsigned)lane * 16u;
@@ -107,7 +110,7 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
     kg_f4 acc[KG_GEMM_ROWS / 16];
 #pragma unroll
     for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) acc[cb] = kg_f4{0.f, 0.f, 0.f, 0.f};
-    // All four column blocks always run (rows past M are zeros in LDS): a branch per block would
+    // All column blocks always run (rows past M are zeros in LDS): a branch per block would
     // put every LDS read right in front of its MFMA with a full wait in between.
     auto compute = [&](const kg_u4 (&wv)[GEMM_KB], const char* xs) {
         kg_u4 x[GEMM_KB][KG_GEMM_ROWS / 16];
@@ -144,7 +147,7 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
         stage_store(sx[0], gw[0], xs0);
         stage_load(sx[0], gw[0], XS);
         __syncthreads();
-        for (int b = 0; b < NB; b += U) {
+        for (int b = 0; b < NBL; b += U) {
 #pragma unroll
             for (int i = 0; i < U; ++i) {
                 const int bb = b + i;
@@ -165,7 +168,7 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
         for (int i = 0; i < D - 1; ++i) issue_w(w[i], i);
         __syncthreads();
         KG_TSTAMP(a, 1);
-        for (int b = 0; b < NB; b += U) {      // batches past the last one: zeros in, zeros added
+        for (int b = 0; b < NBL; b += U) {      // batches past the last one: zeros in, zeros added
 #pragma unroll
             for (int i = 0; i < U; ++i) {
                 const int bb = b + i;
@@ -204,6 +207,23 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
     }
     // ---- epilogue inputs through LDS (the X buffers are free now), laid out as the decode epilogues expect ----
     char* side = (EPI == EPI_RESID) ? xs0 + (size_t)(loader ? 0 : wave) * KG_GEMM_ROWS * 32 : xs0;
+    if (EPI == EPI_RESID && KS > 1) {
+        // partial sums of this K range; kg_gemm_reduce_kernel adds the ranges and the residual
+        if (loader || rg >= G) return;
+        float* part = a.kpart + (size_t)blockIdx.y * KG_GEMM_ROWS * a.N;
+#pragma unroll
+        for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) {
+            const int m = 16 * cb + r;
+            if (m < M) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = rg * 16 + 4 * g + i;
+                    if (n < a.N) part[(size_t)m * a.N + n] = acc[cb][i];
+                }
+            }
+        }
+        return;
+    }
     if (EPI == EPI_RESID && !loader) {
         const unsigned short* res = (const unsigned short*)a.resid;
         for (int e = lane; e < M * 16; e += 64) {
@@ -234,13 +254,36 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
     KG_TSTAMP(a, 7);
 }
 
+// out[m][n] = round16(resid[m][n] + round16(sum over K ranges of part[s][m][n])): the EPI_RESID epilogue
+// of a K-split pass, ranges added in order.
+template <int DT>
+__global__ void kg_gemm_reduce_kernel(const KgLinArgs a) {
+    typedef KgT<DT> T;
+    const KgDyn* dyn = a.dyn;
+    if (dyn->active == 0) return;
+    const int M = dyn->n_rows;
+    const int m = blockIdx.y;
+    if (m >= M) return;
+    const unsigned short* res = (const unsigned short*)a.resid + (size_t)m * a.resid_stride;
+    unsigned short* out = (unsigned short*)a.out + (size_t)m * a.out_stride;
+    // four consecutive columns per thread (N is a multiple of 16 here: the launcher checks)
+    const int n = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (n >= a.N) return;
+    kg_f4 p[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) p[s] = (s < a.ksplit) ? *(const kg_f4*)(a.kpart + ((size_t)s * KG_GEMM_ROWS + m) * a.N + n) : kg_f4{0.f, 0.f, 0.f, 0.f};
+    const kg_f4 v = ((p[0] + p[1]) + p[2]) + p[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[n + i] = T::from_f(T::to_f(res[n + i]) + kg_round<DT>(v[i]));
+}
+
 static int g_gemm_ncu = 256;
 static size_t gemm_smem() { return (size_t)2 * KG_GEMM_ROWS * GEMM_XROW + KG_GEMM_ROWS * sizeof(float); }
 
 template <int DT, int PRO, int NW>
 static int launch_epi(const KgLinArgs& a, int epi, hipStream_t st) {
     const int G = (a.N + 15) / 16;
-    const dim3 grid((G + NW - 1) / NW), block((NW + GEMM_LW) * 64);
+    const dim3 grid((G + NW - 1) / NW, a.ksplit > 1 ? a.ksplit : 1), block((NW + GEMM_LW) * 64);
     const size_t smem = gemm_smem();
     switch (epi) {
     case EPI_STORE: hipLaunchKernelGGL((kg_gemm_kernel<DT, PRO, EPI_STORE, NW>), grid, block, smem, st, a); break;
@@ -253,18 +296,47 @@ static int launch_epi(const KgLinArgs& a, int epi, hipStream_t st) {
 }
 template <int DT, int PRO>
 static int launch_nw(const KgLinArgs& a, int epi, hipStream_t st) {
-    const int G = (a.N + 15) / 16;
-    return (G >= 4 * g_gemm_ncu / 2) ? launch_epi<DT, PRO, 4>(a, epi, st) : launch_epi<DT, PRO, 2>(a, epi, st);
+    // Row groups per block (= compute waves): a block's step costs about as much LDS and MFMA time as it
+    // has compute waves, and the launch takes ceil(blocks / CUs) rounds of blocks, so pick the count that
+    // minimises rounds x waves (768 groups: 3 -> 256 blocks in one round; 1376: 3 -> two rounds of 3).
+    const int units = ((a.N + 15) / 16);
+    int best = 2, best_cost = 1 << 30;
+    for (int nw = 4; nw >= 2; --nw) {
+        const int blocks = (units + nw - 1) / nw * (a.ksplit > 1 ? a.ksplit : 1);
+        const int cost = ((blocks + g_gemm_ncu - 1) / g_gemm_ncu) * nw;
+        if (cost < best_cost) { best_cost = cost; best = nw; }
+    }
+    const char* force = getenv("KG_GEMM_NW");
+    if (force) best = atoi(force);
+    switch (best) {
+    case 4: return launch_epi<DT, PRO, 4>(a, epi, st);
+    case 3: return launch_epi<DT, PRO, 3>(a, epi, st);
+    default: return launch_epi<DT, PRO, 2>(a, epi, st);
+    }
 }
 
 // Rows and positions come from a.dyn: n_rows <= KG_GEMM_ROWS rows at positions pos[0], pos[0]+1, ...
-int kg_launch_gemm(const KgLinArgs& a, int dtype, int pro, int epi, hipStream_t st) {
+int kg_launch_gemm(const KgLinArgs& a_in, int dtype, int pro, int epi, hipStream_t st) {
+    KgLinArgs a = a_in;
     if (a.K % 32 != 0 || a.K <= 0 || a.N <= 0) return -1;
+    // Few row groups (the d-row projections): one wave per group over all of K leaves most of the
+    // machine without a weight request in flight, so K is cut into up to 4 ranges on grid.y.
+    {
+        const int G = (a.N + 15) / 16, NB = ((a.K >> 5) + GEMM_KB - 1) / GEMM_KB;
+        int ks = 1;
+        if (epi == EPI_RESID && pro == PRO_NONE && a.kpart && G <= 2 * g_gemm_ncu && a.N % 16 == 0) ks = NB >= 16 ? 4 : (NB >= 8 ? 2 : 1);
+        a.ksplit = ks;
+    }
     if (epi == EPI_ROPE_KV && (size_t)KG_GEMM_ROWS * a.head_dim * 4 > (size_t)2 * KG_GEMM_ROWS * GEMM_XROW) return -1;     // cos/sin rows reuse both X buffers
     int rc;
     if (dtype == KG_F16) rc = (pro == PRO_NONE) ? launch_nw<KG_F16, PRO_NONE>(a, epi, st) : launch_nw<KG_F16, PRO_RMSNORM>(a, epi, st);
     else rc = (pro == PRO_NONE) ? launch_nw<KG_BF16, PRO_NONE>(a, epi, st) : launch_nw<KG_BF16, PRO_RMSNORM>(a, epi, st);
     if (rc) return rc;
+    if (a.ksplit > 1) {
+        const dim3 grid((a.N / 4 + 255) / 256, KG_GEMM_ROWS);
+        if (dtype == KG_F16) hipLaunchKernelGGL(kg_gemm_reduce_kernel<KG_F16>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(kg_gemm_reduce_kernel<KG_BF16>, grid, dim3(256), 0, st, a);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -280,6 +352,8 @@ void kg_gemm_init() {
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) g_gemm_ncu = ncu;
     set_attr_all<KG_F16, PRO_NONE, 2>(); set_attr_all<KG_F16, PRO_RMSNORM, 2>();
     set_attr_all<KG_BF16, PRO_NONE, 2>(); set_attr_all<KG_BF16, PRO_RMSNORM, 2>();
+    set_attr_all<KG_F16, PRO_NONE, 3>(); set_attr_all<KG_F16, PRO_RMSNORM, 3>();
+    set_attr_all<KG_BF16, PRO_NONE, 3>(); set_attr_all<KG_BF16, PRO_RMSNORM, 3>();
     set_attr_all<KG_F16, PRO_NONE, 4>(); set_attr_all<KG_F16, PRO_RMSNORM, 4>();
     set_attr_all<KG_BF16, PRO_NONE, 4>(); set_attr_all<KG_BF16, PRO_RMSNORM, 4>();
     (void)hipGetLastError();

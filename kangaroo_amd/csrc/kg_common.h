@@ -4,7 +4,7 @@
 #include <stdint.h>
 
 #define KG_MAX_ROWS 16          // rows one M-row pass can carry (verify needs steps+1 <= 7)
-#define KG_GEMM_ROWS 64         // rows one prefill (GEMM) pass can carry
+#define KG_GEMM_ROWS 128        // rows one prefill (GEMM) pass can carry
 #define KG_TILE_ROWS 16         // weight rows per packed tile
 #define KG_TILE_K 32            // k elements per packed tile
 #define KG_TILE_ELEMS 512       // 16 x 32 elements = 1 KiB of 16-bit weights

@@ -26,6 +26,9 @@ struct KgLinArgs {
     void* logits_out; int logits_stride;            // optional
     int gx_slot_rows;                               // set by the launcher: rows of a wave's X slot (large-K MFMA mode)
     int side_bytes;                                 // set by the launcher: LDS bytes of staged epilogue inputs
+    // prefill GEMM, EPI_RESID with few row groups: K cut into ksplit ranges on grid.y, fp32 partials
+    // [ksplit][KG_GEMM_ROWS][N] summed in range order by a second kernel (0 / NULL: one range)
+    float* kpart; int ksplit;
 };
 
 size_t kg_linear_smem(int mfma, int max_rows, int K, int nwaves);

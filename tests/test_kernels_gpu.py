@@ -38,7 +38,7 @@ DTYPES = [(torch.float16, _lib.DT_F16), (torch.bfloat16, _lib.DT_BF16)]
 
 @pytest.mark.parametrize("dtype,code", DTYPES, ids=["f16", "bf16"])
 @pytest.mark.parametrize("N,K", [(64, 64), (100, 96), (4096, 4096), (1024, 11008), (2000, 2048)])
-@pytest.mark.parametrize("rows", [1, 2, 7, 16, 17, 40, 64])      # > 16: the prefill GEMM kernel
+@pytest.mark.parametrize("rows", [1, 2, 7, 16, 17, 40, 64, 100, 128])      # > 16: the prefill GEMM kernel
 def test_linear_store(dtype, code, N, K, rows):
     lib = _lib.lib()
     g = torch.Generator().manual_seed(N * 7 + K + rows)
@@ -58,7 +58,7 @@ def test_linear_store(dtype, code, N, K, rows):
 
 
 @pytest.mark.parametrize("dtype,code", DTYPES, ids=["f16", "bf16"])
-@pytest.mark.parametrize("rows", [1, 5, 33, 64])
+@pytest.mark.parametrize("rows", [1, 5, 33, 64, 128])
 def test_linear_rmsnorm_resid_silu(dtype, code, rows):
     lib = _lib.lib()
     d, F = 256, 704
@@ -90,7 +90,7 @@ def test_linear_rmsnorm_resid_silu(dtype, code, rows):
 
 @pytest.mark.parametrize("dtype,code", DTYPES, ids=["f16", "bf16"])
 @pytest.mark.parametrize("H,Hkv,hd", [(4, 2, 16), (8, 8, 32), (4, 1, 64), (32, 32, 128)])
-@pytest.mark.parametrize("rows,pos0", [(1, 0), (1, 37), (2, 5), (7, 130), (16, 0), (16, 48), (40, 3), (64, 100)])
+@pytest.mark.parametrize("rows,pos0", [(1, 0), (1, 37), (2, 5), (7, 130), (16, 0), (16, 48), (40, 3), (64, 100), (100, 20), (128, 100)])
 def test_qkv_rope_attention(dtype, code, H, Hkv, hd, rows, pos0):
     """Fused RMSNorm+QKV+RoPE+append, then attention, against the oracle's attention()."""
     lib = _lib.lib()
@@ -170,6 +170,6 @@ def test_bad_arguments_are_refused():
     lib = _lib.lib()
     t = torch.zeros(1024, dtype=torch.float16, device=DEV)
     assert lib.kg_linear(0, vp(t), 16, 48, vp(t), 1, 0, None, 0.0, 0, None, vp(t), 16, vp(t), 0, 0, stream()) != 0   # K % 32
-    assert lib.kg_linear(0, vp(t), 16, 64, vp(t), 65, 0, None, 0.0, 0, None, vp(t), 16, vp(t), 0, 0, stream()) != 0  # rows
+    assert lib.kg_linear(0, vp(t), 16, 64, vp(t), 129, 0, None, 0.0, 0, None, vp(t), 16, vp(t), 0, 0, stream()) != 0  # rows
     assert lib.kg_linear(0, vp(t), 16, 64, vp(t), 1, 1, None, 0.0, 0, None, vp(t), 16, vp(t), 0, 0, stream()) != 0   # norm_w
     assert b"" != lib.kg_last_error()
