@@ -32,38 +32,45 @@ struct KgAttnCombineLds {
 // run by the `nthr` threads tid = 0..nthr-1 of one team, which share `cl`.  EVERY thread of the block
 // must make the call (it contains a block barrier); teams with active == false only keep it company.
 // The partials come from memory with device-coherent loads, each a round trip of a microsecond
-// or more, so they are requested in bulk: first every (max, sum) pair, then for each output
-// element its ns partial sums, 8 splits at a time, before anything waits.  The sums run in split
-// order.
+// or more, and a block can issue only one wave-level load every few cycles, so they are requested
+// in bulk and wide: each thread takes four consecutive output elements of a row (one 16-byte load per
+// split), only the ns splits in use are touched, and everything is in flight before anything
+// waits.  The sums run in split order.  hd is a multiple of 4.
 template <int DT, bool COH>
 __device__ __forceinline__ void split_combine(const KgAttnArgs& a, int h, int hd, int m0, int mr, int ns, int tid, int nthr,
                                               KgAttnCombineLds& cl, bool active) {
     typedef KgT<DT> T;
-    // the first 16 splits' partial sums of this thread's (up to four) output elements: requested
-    // before anything else, so that they travel together with phase A's (max, sum) pairs
-    const int total = active ? mr * hd : 0;
-    float v[4][16];
-    auto load_v = [&](int i0, int s0) {
+    constexpr int SB = 8;                             // splits per batch of loads
+    const int hq = hd >> 2;                           // quads per row
+    const int nq = active ? mr * hq : 0;              // quads of this head's output rows
+    const size_t sstride = (size_t)a.max_rows * a.H * hd;       // floats between consecutive splits
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)a.part_o, 0, (int)((size_t)ns * sstride * 4 > 0x7fffffffu ? 0x7fffffffu : (size_t)ns * sstride * 4), 0x00020000);
+    kg_f4 v[2][SB];
+    auto quad_off = [&](int q) {                      // float offset of quad q inside split 0
+        const int ml = q / hq, dq = q - ml * hq;
+        return ((size_t)(m0 + ml) * a.H + h) * hd + 4 * dq;
+    };
+    auto load_v = [&](int q0, int s0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = i0 + k * nthr + tid;
-            const int ml = (i < total) ? i / hd : 0, dmi = (i < total) ? i % hd : 0;
+        for (int k = 0; k < 2; ++k) {
+            const int q = q0 + k * nthr + tid;
+            const unsigned base = (q < nq) ? (unsigned)(quad_off(q) * 4) : 0xFFFFFFFFu;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int s = (s0 + j < ns) ? s0 + j : 0;
-                v[k][j] = coh_load(a.part_o + (((size_t)s * a.max_rows + m0 + ml) * a.H + h) * hd + dmi);
-            }
+            for (int j = 0; j < SB; ++j)
+                if (s0 + j < ns) v[k][j] = __builtin_bit_cast(kg_f4, __builtin_amdgcn_raw_buffer_load_b128(pr, (q < nq) ? base + (unsigned)((s0 + j) * sstride * 4) : 0xFFFFFFFFu, 0, KG_AUX_COH));
         }
     };
-    if (total > 0) load_v(0, 0);
+    if (nq > 0) load_v(0, 0);
     // phase A: one thread per row
     if (active && tid < mr) {
         const int m = m0 + tid;
         float ms[KG_ATTN_MAX_SPLITS], ls[KG_ATTN_MAX_SPLITS];
 #pragma unroll
         for (int s = 0; s < KG_ATTN_MAX_SPLITS; ++s) {
-            const float* ml = a.part_ml + (((size_t)(s < ns ? s : 0) * a.max_rows + m) * a.H + h) * 2;
-            ms[s] = coh_load(ml); ls[s] = coh_load(ml + 1);
+            if (s < ns) {
+                const unsigned long long u = __hip_atomic_load((const unsigned long long*)(a.part_ml + (((size_t)s * a.max_rows + m) * a.H + h) * 2), __ATOMIC_RELAXED, KG_AGENT);
+                ms[s] = __uint_as_float((unsigned)u); ls[s] = __uint_as_float((unsigned)(u >> 32));
+            }
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -80,28 +87,40 @@ __device__ __forceinline__ void split_combine(const KgAttnArgs& a, int h, int hd
         cl.l[tid] = l;
     }
     __syncthreads();
-    // phase B: output elements i = tid + nthr * k
-    for (int i0 = 0; i0 < total; i0 += 4 * nthr) {
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int s0 = 0; s0 < ns; s0 += 16) {
-            if (i0 > 0 || s0 > 0) load_v(i0, s0);
+    // phase B: quads q = tid + nthr * k
+    for (int q0 = 0; q0 < nq; q0 += 2 * nthr) {
+        kg_f4 o[2] = {kg_f4{0.f, 0.f, 0.f, 0.f}, kg_f4{0.f, 0.f, 0.f, 0.f}};
+        for (int s0 = 0; s0 < ns; s0 += SB) {
+            if (q0 > 0 || s0 > 0) load_v(q0, s0);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = i0 + k * nthr + tid;
-                const int ml = (i < total) ? i / hd : 0;
+            for (int k = 0; k < 2; ++k) {
+                const int q = q0 + k * nthr + tid;
+                const int ml = (q < nq) ? q / hq : 0;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) if (s0 + j < ns) o[k] += cl.f[s0 + j][ml] * v[k][j];
+                for (int j = 0; j < SB; ++j)
+                    if (s0 + j < ns) {
+                        const float f = cl.f[s0 + j][ml];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[k][e] += f * v[k][j][e];
+                    }
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = i0 + k * nthr + tid;
-            if (i < total) {
-                const int ml = i / hd, dmi = i % hd;
-                unsigned short* dst = (unsigned short*)a.out + (size_t)(m0 + ml) * a.H * hd + (size_t)h * hd + dmi;
-                const unsigned short r = T::from_f(o[k] / cl.l[ml]);
-                if (COH) __hip_atomic_store(dst, r, __ATOMIC_RELAXED, KG_AGENT);
-                else *dst = r;
+        for (int k = 0; k < 2; ++k) {
+            const int q = q0 + k * nthr + tid;
+            if (q < nq) {
+                const int ml = q / hq, dq = q - ml * hq;
+                unsigned short* dst = (unsigned short*)a.out + (size_t)(m0 + ml) * a.H * hd + (size_t)h * hd + 4 * dq;
+                const float linv = cl.l[ml];
+                unsigned short r[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = T::from_f(o[k][e] / linv);
+                if (COH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) __hip_atomic_store(dst + e, r[e], __ATOMIC_RELAXED, KG_AGENT);
+                } else {
+                    *(unsigned long long*)dst = (unsigned long long)r[0] | ((unsigned long long)r[1] << 16) | ((unsigned long long)r[2] << 32) | ((unsigned long long)r[3] << 48);
+                }
             }
         }
     }
