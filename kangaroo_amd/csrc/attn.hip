@@ -294,24 +294,30 @@ __global__ void __launch_bounds__(NT * ATT_NW * 64) kg_attn_mfma_kernel(const Kg
         }
         __syncthreads();
         if (valid) {
-            for (int i = ttid; i < M * HD; i += ATT_NW * 64) {
-                const int m = i / HD, dmi = i - m * HD;
+            // one thread per (row, four consecutive head dims): M * HD / 4 <= 512 quads for the team's 256 threads
+            for (int q = ttid; q < M * (HD / 4); q += ATT_NW * 64) {
+                const int m = q / (HD / 4), dmi = 4 * (q - m * (HD / 4));
                 float mx = -INFINITY;
 #pragma unroll
                 for (int w = 0; w < ATT_NW; ++w) mx = fmaxf(mx, lds.ml[w][m][0]);
-                float o = 0.f, l = 0.f;
+                kg_f4 o = kg_f4{0.f, 0.f, 0.f, 0.f};
+                float l = 0.f;
 #pragma unroll
                 for (int w = 0; w < ATT_NW; ++w) {
                     const float wm = lds.ml[w][m][0];
                     const float fw = (wm == -INFINITY) ? 0.f : expf(wm - mx);
-                    o += fw * lds.o[w][m][dmi];
+                    const kg_f4 ow = *(const kg_f4*)&lds.o[w][m][dmi];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += fw * ow[e];
                     l += fw * lds.ml[w][m][1];
                 }
                 if (local) {
-                    pl_o[((size_t)(ch - c0) * M + m) * HD + dmi] = o;
+                    *(kg_f4*)&pl_o[((size_t)(ch - c0) * M + m) * HD + dmi] = o;
                     if (dmi == 0) { pl_ml[((ch - c0) * M + m) * 2] = mx; pl_ml[((ch - c0) * M + m) * 2 + 1] = l; }
                 } else {
-                    coh_store(a.part_o + (((size_t)ch * a.max_rows + row0 + m) * a.H + h) * HD + dmi, o);
+                    float* dst = a.part_o + (((size_t)ch * a.max_rows + row0 + m) * a.H + h) * HD + dmi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) coh_store(dst + e, o[e]);
                     if (dmi == 0) {
                         float* ml = a.part_ml + (((size_t)ch * a.max_rows + row0 + m) * a.H + h) * 2;
                         coh_store(ml, mx); coh_store(ml + 1, l);
