@@ -97,7 +97,8 @@ __device__ __forceinline__ void rec_merge(HeadRec& a, const HeadRec& b) {
 __device__ HeadRec head_reduce_row(const float* part, int nblocks, float* s_mx, float* s_sum, int* s_idx) {
     HeadRec r; r.mx = -INFINITY; r.sum = 0.f; r.idx = 0x7fffffff;
     for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
-        HeadRec o; o.mx = part[b * 4]; o.sum = part[b * 4 + 1]; o.idx = __float_as_int(part[b * 4 + 2]);
+        const kg_f4 v = *(const kg_f4*)(part + (size_t)b * 4);      // one record: (max, sum, argmax bits, -)
+        HeadRec o; o.mx = v[0]; o.sum = v[1]; o.idx = __float_as_int(v[2]);
         rec_merge(r, o);
     }
 #pragma unroll
@@ -141,11 +142,12 @@ __device__ __forceinline__ double kg_thresh(const int* st) {
     return __builtin_bit_cast(double, b);
 }
 
-__global__ void kg_round_begin_kernel(KgLoopBufs b) {
-    int* st = b.state;
-    if (threadIdx.x != 0) return;
-    const int s = st[KS_START], steps = st[KS_STEPS];
-    const int alive = (st[KS_STOP] == 0) && (s < st[KS_MAX_INFER] - 1 - steps);     // :46
+// Start-of-round state for the round that begins at start index s (:46-49): run by one thread, at the end
+// of the previous round's accept kernel (and once after the prefill).  Also presets the verify pass's
+// rows (positions s, s+1, ...; one row until a draft step adds more).
+__device__ __forceinline__ void kg_round_begin_state(const KgLoopBufs& b, int* st, int s, int stop) {
+    const int steps = st[KS_STEPS];
+    const int alive = (stop == 0) && (s < st[KS_MAX_INFER] - 1 - steps);             // :46
     st[KS_ALIVE] = alive;
     st[KS_END] = s + 1;                                                              // :49
     st[KS_DRAFTED] = 0;
@@ -153,9 +155,20 @@ __global__ void kg_round_begin_kernel(KgLoopBufs b) {
     b.dyn_shallow->active = alive;
     b.dyn_shallow->n_rows = 1;
     b.dyn_shallow->pos[0] = s;                                                       // token at end_index-1
+    KgDyn* dv = b.dyn_verify;                                                        // rows s .. e-1 (:86-89)
+    dv->active = alive;
+    dv->n_rows = 1;
+#pragma unroll
+    for (int i = 0; i < KG_MAX_ROWS; ++i) dv->pos[i] = s + i;
+}
+__global__ void kg_round_begin_kernel(KgLoopBufs b) {
+    int* st = b.state;
+    if (threadIdx.x != 0) return;
+    kg_round_begin_state(b, st, st[KS_START], st[KS_STOP]);
 }
 
-// after the shallow pass of `step`: adapter rows and positions (:55-61, :70-71)
+// after the shallow pass of step 0: adapter rows and positions (:55-61, :70-71); later steps get theirs
+// from the previous step's kg_step_end_kernel
 __global__ void kg_step_mid_kernel(KgLoopBufs b, int step) {
     int* st = b.state;
     const int on = st[KS_DRAFT_ON];
@@ -186,7 +199,7 @@ __global__ void kg_step_end_kernel(KgLoopBufs b, int step, const float* head_par
     int* st = b.state;
     const int on = st[KS_DRAFT_ON];          // uniform
     if (!on) {
-        if (threadIdx.x == 0) b.dyn_shallow->active = 0;
+        if (threadIdx.x == 0) { b.dyn_shallow->active = 0; b.dyn_adapter->active = 0; }
         return;
     }
     HeadRec r = head_reduce_row(head_part, nblocks, s_mx, s_sum, s_idx);
@@ -208,17 +221,13 @@ __global__ void kg_step_end_kernel(KgLoopBufs b, int step, const float* head_par
         b.dyn_shallow->active = 1;
         b.dyn_shallow->n_rows = 1;
         b.dyn_shallow->pos[0] = e;                            // the token just drafted
+        b.dyn_verify->n_rows = e + 1 - st[KS_START];          // the verify pass covers positions s .. e (:86-89)
+        // the next step's adapter pass: one row, the token just drafted (:60, :77)
+        KgDyn* da = b.dyn_adapter;
+        da->active = brk ? 0 : 1;
+        da->n_rows = 1;
+        da->pos[0] = e;
     }
-}
-
-// rows of the verify pass: positions s .. e-1 (:86-89)
-__global__ void kg_verify_begin_kernel(KgLoopBufs b) {
-    int* st = b.state;
-    const int i = threadIdx.x;
-    const int s = st[KS_START], e = st[KS_END];
-    KgDyn* d = b.dyn_verify;
-    if (i == 0) { d->active = st[KS_ALIVE]; d->n_rows = e - s; }
-    if (i < KG_MAX_ROWS) d->pos[i] = s + i;
 }
 
 // Top-k verification (evaluation/inference_kangaroo_MTBench.py:377-389): rank[i] = how many verify
@@ -311,15 +320,47 @@ __global__ void kg_topp_member_kernel(KgLoopBufs b, const unsigned short* logits
 // a drafted token survives while rank[i] < top_k (kg_topk_rank_kernel); top_k == 0: while it lies in the
 // pooled top-p nuclei, rank + KG_MAX_ROWS holding kg_topp_member_kernel's table.
 __global__ void kg_accept_kernel(KgLoopBufs b, const float* head_part, int stride, int nblocks, const int* rank, int top_k) {
-    __shared__ float s_mx[8], s_sum[8]; __shared__ int s_idx[8];
     __shared__ int s_tok[KG_MAX_ROWS];
     int* st = b.state;
     if (st[KS_ALIVE] == 0) return;
     const int s = st[KS_START], e = st[KS_END];
     const int q = e - s;
-    for (int m = 0; m < q; ++m) {
-        HeadRec r = head_reduce_row(head_part + (size_t)m * stride * 4, nblocks, s_mx, s_sum, s_idx);
-        if (threadIdx.x == 0) { s_tok[m] = r.idx; b.head_tok[m] = r.idx; }
+    // argmax of every verify row (:92): wave w reduces rows w, w + 4, ...; the records of all its rows
+    // are requested before any is used (one memory round trip for the whole kernel instead of one per row)
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        constexpr int RW = KG_MAX_ROWS / 4, PL = 4;             // rows per wave, records per lane held at once
+        kg_f4 rec[RW][PL];
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            const int m = wave + 4 * j;
+#pragma unroll
+            for (int k = 0; k < PL; ++k) {
+                const int blk = lane + 64 * k;
+                rec[j][k] = (m < q && blk < nblocks) ? *(const kg_f4*)(head_part + ((size_t)m * stride + blk) * 4) : kg_f4{-INFINITY, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            const int m = wave + 4 * j;
+            if (m >= q) continue;                               // wave-uniform
+            HeadRec r; r.mx = -INFINITY; r.sum = 0.f; r.idx = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < PL; ++k) {
+                if (lane + 64 * k < nblocks) { HeadRec o; o.mx = rec[j][k][0]; o.sum = rec[j][k][1]; o.idx = __float_as_int(rec[j][k][2]); rec_merge(r, o); }
+            }
+            for (int blk = lane + 64 * PL; blk < nblocks; blk += 64) {
+                const kg_f4 v = *(const kg_f4*)(head_part + ((size_t)m * stride + blk) * 4);
+                HeadRec o; o.mx = v[0]; o.sum = v[1]; o.idx = __float_as_int(v[2]);
+                rec_merge(r, o);
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                HeadRec t; t.mx = __shfl_xor(r.mx, o, 64); t.sum = __shfl_xor(r.sum, o, 64); t.idx = __shfl_xor(r.idx, o, 64);
+                rec_merge(r, t);
+            }
+            if (lane == 0) { s_tok[m] = r.idx; b.head_tok[m] = r.idx; }
+        }
     }
     __syncthreads();
     // keep the last early-exit row for the adapter's missing-cache patch of the next round (:58)
@@ -361,6 +402,7 @@ __global__ void kg_accept_kernel(KgLoopBufs b, const float* head_part, int strid
         // base caches: slot == position, everything at slots >= snew is dead and gets
         // overwritten; the adapter cache is tracked by length (:114-118)
         if (st[KS_ADAPTER_LEN] > snew) st[KS_ADAPTER_LEN] = snew;
+        kg_round_begin_state(b, st, snew, stop);              // the next round's :46-49
     }
 }
 
@@ -393,7 +435,6 @@ __global__ void kg_vanilla_end_kernel(KgLoopBufs b, const float* head_part, int 
 int kg_launch_round_begin(const KgLoopBufs& b, hipStream_t st) { KG_L1(kg_round_begin_kernel, b); }
 int kg_launch_step_mid(const KgLoopBufs& b, int step, hipStream_t st) { KG_L1(kg_step_mid_kernel, b, step); }
 int kg_launch_step_end(const KgLoopBufs& b, int step, const float* head_part, int nblocks, hipStream_t st) { KG_L1(kg_step_end_kernel, b, step, head_part, nblocks); }
-int kg_launch_verify_begin(const KgLoopBufs& b, hipStream_t st) { KG_L1(kg_verify_begin_kernel, b); }
 int kg_launch_accept(const KgLoopBufs& b, const float* head_part, int stride, int nblocks, const int* rank, int top_k, hipStream_t st) { KG_L1(kg_accept_kernel, b, head_part, stride, nblocks, rank, top_k); }
 int kg_launch_topp_member(const KgLoopBufs& b, const void* logits, int vocab, float temperature, float top_p, int* member, int dtype, hipStream_t st) {
     if (dtype == KG_F16) hipLaunchKernelGGL(kg_topp_member_kernel<KG_F16>, dim3(KG_MAX_ROWS), dim3(256), 0, st, b, (const unsigned short*)logits, vocab, temperature, top_p, member);

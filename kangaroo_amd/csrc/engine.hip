@@ -596,7 +596,8 @@ static int enqueue_round(kg_session* s, int steps, hipStream_t st) {
     const int d = sh.hidden_size, L = sh.exit_layer, N = sh.num_layers;
     const size_t rowb = (size_t)d * s->elt;
     KgLoopBufs b = loop_bufs(s);
-    KG_TRY(kg_launch_round_begin(b, st));
+    // the round's start state was left by the previous round's accept kernel (kg_generate: by a
+    // kg_round_begin launch after the prefill)
     for (int k = 0; k <= steps; ++k) {
         // shallow pass on the newest token -> exited[k]
         KG_TRY(kg_launch_embed(s->dyn_shallow, s->tokens, s->w.embed, d, s->h, d, st));
@@ -607,7 +608,7 @@ static int enqueue_round(kg_session* s, int steps, hipStream_t st) {
             cur = dst;
         }
         if (k == steps) break;
-        KG_TRY(kg_launch_step_mid(b, k, st));
+        if (k == 0) KG_TRY(kg_launch_step_mid(b, k, st));
         if (k == 0) {
             KG_TRY(run_layer(s, s->w.adapter, s->buf.ak_cache, s->buf.av_cache, s->dyn_adapter, 2, s->adapter_in, s->adapter_h, st));
         } else {
@@ -617,7 +618,6 @@ static int enqueue_round(kg_session* s, int steps, hipStream_t st) {
         KG_TRY(run_head(s, s->dyn_adapter, 1, s->adapter_h, 1, s->w.adapter_norm, nullptr, &nb, st));
         KG_TRY(kg_launch_step_end(b, k, s->head_part, nb, st));
     }
-    KG_TRY(kg_launch_verify_begin(b, st));
     const int vrows = steps + 1 > 1 ? steps + 1 : 2;
     int nb = 0;
     if (s->prog_n[0] > 0) {
@@ -808,6 +808,7 @@ extern "C" int kg_generate(kg_session* s, int mode, const int32_t* prompt_host, 
     KG_CHECK_HIP(hipMemcpyAsync(s->state + KS_EOS, hs + 32, sizeof(int), hipMemcpyHostToDevice, st));
     KG_CHECK_HIP(hipMemcpyAsync(s->state + KS_ROUND, hs + 33, sizeof(int), hipMemcpyHostToDevice, st));
     KG_CHECK_HIP(hipMemcpyAsync(s->state + KS_STOP, hs + 33, sizeof(int), hipMemcpyHostToDevice, st));
+    if (mode == 0) KG_TRY(kg_launch_round_begin(loop_bufs(s), st));
     KG_CHECK_HIP(hipEventRecord(s->ev_t1, st));
 
     hipGraphExec_t ge = (mode == 0) ? s->round_graph : s->vanilla_graph;
