@@ -142,6 +142,14 @@ __device__ __forceinline__ double kg_thresh(const int* st) {
     return __builtin_bit_cast(double, b);
 }
 
+// h[:] = embed[tok][:]: the input row of the next shallow pass (all threads of the block)
+__device__ __forceinline__ void kg_gather_embed(const KgLoopBufs& b, int tok) {
+    const int n16 = b.d * b.elt / 16;
+    const kg_u4* src = (const kg_u4*)b.embed + (size_t)tok * n16;
+    kg_u4* dst = (kg_u4*)b.h;
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+}
+
 // Start-of-round state for the round that begins at start index s (:46-49): run by one thread, at the end
 // of the previous round's accept kernel (and once after the prefill).  Also presets the verify pass's
 // rows (positions s, s+1, ...; one row until a draft step adds more).
@@ -163,8 +171,10 @@ __device__ __forceinline__ void kg_round_begin_state(const KgLoopBufs& b, int* s
 }
 __global__ void kg_round_begin_kernel(KgLoopBufs b) {
     int* st = b.state;
+    const int s = st[KS_START];
+    kg_gather_embed(b, b.tokens[s]);
     if (threadIdx.x != 0) return;
-    kg_round_begin_state(b, st, st[KS_START], st[KS_STOP]);
+    kg_round_begin_state(b, st, s, st[KS_STOP]);
 }
 
 // after the shallow pass of step 0: adapter rows and positions (:55-61, :70-71); later steps get theirs
@@ -203,6 +213,7 @@ __global__ void kg_step_end_kernel(KgLoopBufs b, int step, const float* head_par
         return;
     }
     HeadRec r = head_reduce_row(head_part, nblocks, s_mx, s_sum, s_idx);
+    kg_gather_embed(b, r.idx);                                // the next shallow pass runs on this token
     if (threadIdx.x == 0) {
         const int e = st[KS_END];
         const float score = 1.0f / r.sum;                     // softmax max = exp(0) / sum exp(l - max)
@@ -321,6 +332,7 @@ __global__ void kg_topp_member_kernel(KgLoopBufs b, const unsigned short* logits
 // pooled top-p nuclei, rank + KG_MAX_ROWS holding kg_topp_member_kernel's table.
 __global__ void kg_accept_kernel(KgLoopBufs b, const float* head_part, int stride, int nblocks, const int* rank, int top_k) {
     __shared__ int s_tok[KG_MAX_ROWS];
+    __shared__ int s_next;
     int* st = b.state;
     if (st[KS_ALIVE] == 0) return;
     const int s = st[KS_START], e = st[KS_END];
@@ -389,6 +401,7 @@ __global__ void kg_accept_kernel(KgLoopBufs b, const float* head_part, int strid
                 b.tokens[s + 1 + i] = o;                                              // :98
                 snew = s + 1 + i;                                                     // :99
                 stop = (o == eos);                                                    // :100
+                s_next = o;
                 break;
             }
         }
@@ -404,6 +417,8 @@ __global__ void kg_accept_kernel(KgLoopBufs b, const float* head_part, int strid
         if (st[KS_ADAPTER_LEN] > snew) st[KS_ADAPTER_LEN] = snew;
         kg_round_begin_state(b, st, snew, stop);              // the next round's :46-49
     }
+    __syncthreads();
+    kg_gather_embed(b, s_next);                               // the next round's first shallow pass runs on this token
 }
 
 // ---- vanilla greedy decode: one token per graph replay ----

@@ -398,6 +398,7 @@ static KgLoopBufs loop_bufs(kg_session* s) {
     b.exited = s->exited; b.prev_exit = s->prev_exit; b.adapter_in = s->adapter_in;
     b.head_tok = s->head_tok; b.head_pmax = s->head_pmax;
     b.d = s->sh.hidden_size; b.elt = s->elt;
+    b.embed = s->w.embed; b.h = s->h;
     return b;
 }
 
@@ -599,8 +600,8 @@ static int enqueue_round(kg_session* s, int steps, hipStream_t st) {
     // the round's start state was left by the previous round's accept kernel (kg_generate: by a
     // kg_round_begin launch after the prefill)
     for (int k = 0; k <= steps; ++k) {
-        // shallow pass on the newest token -> exited[k]
-        KG_TRY(kg_launch_embed(s->dyn_shallow, s->tokens, s->w.embed, d, s->h, d, st));
+        // shallow pass on the newest token -> exited[k]; its embedding row was put into s->h by the control
+        // kernel that produced the token (previous step's kg_step_end, previous round's kg_accept)
         const void* cur = s->h;
         for (int l = 0; l < L; ++l) {
             void* dst = (l == L - 1) ? (void*)(s->exited + k * rowb) : (void*)s->h;

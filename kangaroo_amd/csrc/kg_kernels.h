@@ -89,6 +89,8 @@ struct KgLoopBufs {
     int* head_tok;              // [KG_MAX_ROWS] argmax per row of the last head pass
     float* head_pmax;           // [KG_MAX_ROWS]
     int d; int elt;
+    const void* embed;          // [vocab][d] embedding table
+    void* h;                    // [d] input row of the next shallow pass (the control kernels gather it)
 };
 int kg_launch_round_begin(const KgLoopBufs& b, hipStream_t st);
 int kg_launch_step_mid(const KgLoopBufs& b, int step, hipStream_t st);        // after the shallow pass: adapter rows
