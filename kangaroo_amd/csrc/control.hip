@@ -422,27 +422,35 @@ __global__ void kg_accept_kernel(KgLoopBufs b, const float* head_part, int strid
 }
 
 // ---- vanilla greedy decode: one token per graph replay ----
-__global__ void kg_vanilla_begin_kernel(KgLoopBufs b) {
-    int* st = b.state;
-    if (threadIdx.x != 0) return;
-    const int s = st[KS_START];
-    const int alive = (st[KS_STOP] == 0) && (s + 1 < st[KS_MAX_INFER]);
+// state for the token at start index s: run by one thread, after the prefill and at the end of every step
+__device__ __forceinline__ void kg_vanilla_begin_state(const KgLoopBufs& b, int* st, int s, int stop) {
+    const int alive = (stop == 0) && (s + 1 < st[KS_MAX_INFER]);
     st[KS_ALIVE] = alive;
     b.dyn_shallow->active = alive;
     b.dyn_shallow->n_rows = 1;
     b.dyn_shallow->pos[0] = s;
+}
+__global__ void kg_vanilla_begin_kernel(KgLoopBufs b) {
+    int* st = b.state;
+    const int s = st[KS_START];
+    kg_gather_embed(b, b.tokens[s]);
+    if (threadIdx.x != 0) return;
+    kg_vanilla_begin_state(b, st, s, st[KS_STOP]);
 }
 __global__ void kg_vanilla_end_kernel(KgLoopBufs b, const float* head_part, int nblocks) {
     __shared__ float s_mx[8], s_sum[8]; __shared__ int s_idx[8];
     int* st = b.state;
     if (st[KS_ALIVE] == 0) return;
     HeadRec r = head_reduce_row(head_part, nblocks, s_mx, s_sum, s_idx);
+    kg_gather_embed(b, r.idx);                                // input row of the next step
     if (threadIdx.x == 0) {
         const int s = st[KS_START];
+        const int stop = (r.idx == st[KS_EOS]);
         b.tokens[s + 1] = r.idx;
         st[KS_START] = s + 1;
-        st[KS_STOP] = (r.idx == st[KS_EOS]);
+        st[KS_STOP] = stop;
         st[KS_ROUND] = st[KS_ROUND] + 1;
+        kg_vanilla_begin_state(b, st, s + 1, stop);
     }
 }
 

@@ -645,8 +645,8 @@ static int enqueue_vanilla(kg_session* s, hipStream_t st) {
     // token the result is therefore bit-identical to the Kangaroo loop's output.
     const kg_shape& sh = s->sh;
     KgLoopBufs b = loop_bufs(s);
-    KG_TRY(kg_launch_vanilla_begin(b, st));
-    KG_TRY(kg_launch_embed(s->dyn_shallow, s->tokens, s->w.embed, sh.hidden_size, s->h, sh.hidden_size, st));
+    // the step's state and input row were left by the previous step's kg_vanilla_end (kg_generate: by a
+    // kg_vanilla_begin launch after the prefill)
     int nb = 0;
     if (s->prog_n[1] > 0) {
         for (int l = 0; l < sh.exit_layer; ++l)
@@ -810,6 +810,7 @@ extern "C" int kg_generate(kg_session* s, int mode, const int32_t* prompt_host, 
     KG_CHECK_HIP(hipMemcpyAsync(s->state + KS_ROUND, hs + 33, sizeof(int), hipMemcpyHostToDevice, st));
     KG_CHECK_HIP(hipMemcpyAsync(s->state + KS_STOP, hs + 33, sizeof(int), hipMemcpyHostToDevice, st));
     if (mode == 0) KG_TRY(kg_launch_round_begin(loop_bufs(s), st));
+    else KG_TRY(kg_launch_vanilla_begin(loop_bufs(s), st));
     KG_CHECK_HIP(hipEventRecord(s->ev_t1, st));
 
     hipGraphExec_t ge = (mode == 0) ? s->round_graph : s->vanilla_graph;
