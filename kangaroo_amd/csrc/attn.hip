@@ -216,12 +216,17 @@ __global__ void __launch_bounds__(NT * ATT_NW * 64) kg_attn_mfma_kernel(const Kg
     // blockIdx.z selects a block of 16 query rows (prefill passes carry up to KG_GEMM_ROWS rows);
     // rows of a pass sit at consecutive positions
     const int row0 = 16 * blockIdx.z;
-    const int pos_c = dyn->pos[0] + row0 + c;
-    if (dyn->active == 0) return;
-    const int Mtot = dyn->n_rows;
+    // Every scalar the kernel needs (pass parameters from memory, kernel arguments) is fetched in one
+    // batch up front: fetched where first used, each costs a scalar-cache miss of its own in a chain
+    // of dependent waits (measured 2.3 us from entry to the first K/V request; the keys need none of it).
+    const int d_active = dyn->active, Mtot = dyn->n_rows, d_pos0 = dyn->pos[0];
+    asm volatile("" :: "s"(d_active), "s"(Mtot), "s"(d_pos0), "s"(a.H), "s"(a.Hkv), "s"(a.t_max), "s"(a.nsplit), "s"(a.max_rows),
+                 "s"(a.q), "s"(a.k_cache), "s"(a.v_cache), "s"(a.part_o), "s"(a.part_ml), "s"(a.counters), "s"(a.out));
+    const int pos_c = d_pos0 + row0 + c;
+    if (d_active == 0) return;
     if (row0 >= Mtot) return;
     const int M = min(16, Mtot - row0);
-    const int len = dyn->pos[0] + row0 + M;
+    const int len = d_pos0 + row0 + M;
     const int h = blockIdx.x;
     int chunk = (a.t_max + a.nsplit - 1) / a.nsplit;
     chunk = (chunk + 31) / 32 * 32;

@@ -27,4 +27,4 @@ for rows, L in [(7, 128), (7, 256), (7, 512), (7, 2000), (1, 256)]:
     def rel(i, f=np.mean): 
         v = act[:, :, i]; v = v[v > 0]
         return f(v - t0) if v.size else float("nan")
-    print(f"rows {rows} T {L} chunks {nact}: entry mean {rel(0):.2f} max {rel(0, np.max):.2f} | loads issued {rel(1):.2f} | chunk done {rel(2):.2f} max {rel(2, np.max):.2f} | partials stored {rel(3):.2f} | arrived {rel(4):.2f} max {rel(4, np.max):.2f} | [last block] loads issued {rel(5, np.max):.2f} | phase A done {rel(7, np.max):.2f} | end max {rel(6, np.max):.2f}", flush=True)
+    print(f"rows {rows} T {L} chunks {nact}: entry {rel(0):.2f} | params known {rel(1):.2f} | q requested {rel(2):.2f} | first tile requested {rel(3):.2f} | tiles computed {rel(4):.2f} max {rel(4, np.max):.2f}", flush=True)
