@@ -165,7 +165,8 @@ __device__ __forceinline__ void epilogue_pair(const KgLinArgs& a, int n0, int m,
 // factor rsqrt(mean(x^2) + eps) multiplies the finished dot products in the epilogue, after
 // the partial sums of squares have met in LDS at the first row group's barrier.  The norm
 // therefore costs no barrier and no reduction before the weight stream starts.
-template <int RM> struct ProRegs { kg_u4 v[RM]; kg_u4 gw; };
+// NS register slots of 16 bytes: slot i holds chunk set i % SETS of row i / SETS (SETS = chunks of a row per thread)
+template <int NS> struct ProRegs { kg_u4 v[NS]; kg_u4 gw[2]; };
 
 template <int DT, int PRO, int RM, bool COH_LD>
 __device__ __forceinline__ void prologue_slow(const KgLinArgs& a, char* xs, int xs_stride, float (&ss)[RM], int M, int row_off,
@@ -197,44 +198,52 @@ __device__ __forceinline__ void prologue_slow(const KgLinArgs& a, char* xs, int 
     }
 }
 
-template <int PRO, int RM, bool COH_LD>
-__device__ __forceinline__ void prologue_load(const KgLinArgs& a, ProRegs<RM>& pr, int M, int row_off, int tid) {
+template <int PRO, int NS, int SETS, bool COH_LD>
+__device__ __forceinline__ void prologue_load(const KgLinArgs& a, ProRegs<NS>& pr, int M, int row_off, int tid, int nthreads) {
     const int K = a.K, nchunk = K >> 3;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0,
         (int)(((size_t)(M - 1 + row_off) * a.x_stride + K) * 2), 0x00020000);
 #pragma unroll
-    for (int m = 0; m < RM; ++m) {
-        const bool ok = (m < M) && (tid < nchunk);
-        const unsigned off = ok ? (unsigned)(((size_t)(m + row_off) * a.x_stride) * 2 + tid * 16) : 0xFFFFFFFFu;
-        pr.v[m] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, COH_LD ? KG_AUX_COH : 0);
+    for (int i = 0; i < NS; ++i) {
+        const int m = i / SETS, c = tid + (i % SETS) * nthreads;
+        const bool ok = (m < M) && (c < nchunk);
+        const unsigned off = ok ? (unsigned)(((size_t)(m + row_off) * a.x_stride) * 2 + (size_t)c * 16) : 0xFFFFFFFFu;
+        pr.v[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, COH_LD ? KG_AUX_COH : 0);
     }
     if (PRO == PRO_RMSNORM) {
         const __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc((void*)a.norm_w, 0, K * 2, 0x00020000);
-        pr.gw = __builtin_amdgcn_raw_buffer_load_b128(nr, (tid < nchunk) ? (unsigned)tid * 16u : 0xFFFFFFFFu, 0, 0);
+#pragma unroll
+        for (int j = 0; j < SETS; ++j) {
+            const int c = tid + j * nthreads;
+            pr.gw[j] = __builtin_amdgcn_raw_buffer_load_b128(nr, (c < nchunk) ? (unsigned)c * 16u : 0xFFFFFFFFu, 0, 0);
+        }
     }
 }
 
-template <int DT, int PRO, int RM>
-__device__ __forceinline__ void prologue_finish(const KgLinArgs& a, const ProRegs<RM>& pr, char* xs, int xs_stride, float (&ss)[RM], int M,
-                                                int tid) {
+template <int DT, int PRO, int NS, int RM, int SETS>
+__device__ __forceinline__ void prologue_finish(const KgLinArgs& a, const ProRegs<NS>& pr, char* xs, int xs_stride, float (&ss)[RM], int M,
+                                                int tid, int nthreads) {
     typedef KgT<DT> T;
     const int nchunk = a.K >> 3;
-    kg_us8 g = __builtin_bit_cast(kg_us8, pr.gw);
 #pragma unroll
-    for (int m = 0; m < RM; ++m) {
-        if (m < M && tid < nchunk) {
-            if (PRO == PRO_NONE) {
-                *(kg_u4*)(xs + (size_t)m * xs_stride + tid * 16) = pr.v[m];
-            } else {
-                kg_us8 h = __builtin_bit_cast(kg_us8, pr.v[m]);
-                kg_us8 o;
+    for (int i = 0; i < NS; ++i) {
+        const int m = i / SETS, c = tid + (i % SETS) * nthreads;
+        if (i / SETS < RM) {
+            if (m < M && c < nchunk) {
+                if (PRO == PRO_NONE) {
+                    *(kg_u4*)(xs + (size_t)m * xs_stride + (size_t)c * 16) = pr.v[i];
+                } else {
+                    kg_us8 g = __builtin_bit_cast(kg_us8, pr.gw[i % SETS]);
+                    kg_us8 h = __builtin_bit_cast(kg_us8, pr.v[i]);
+                    kg_us8 o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float f = T::to_f(h[j]);
-                    ss[m] += f * f;
-                    o[j] = T::from_f(T::to_f(g[j]) * f);
+                    for (int j = 0; j < 8; ++j) {
+                        const float f = T::to_f(h[j]);
+                        ss[i / SETS < RM ? i / SETS : 0] += f * f;
+                        o[j] = T::from_f(T::to_f(g[j]) * f);
+                    }
+                    *(kg_u4*)(xs + (size_t)m * xs_stride + (size_t)c * 16) = __builtin_bit_cast(kg_u4, o);
                 }
-                *(kg_u4*)(xs + (size_t)m * xs_stride + tid * 16) = __builtin_bit_cast(kg_u4, o);
             }
         }
     }
@@ -331,13 +340,18 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
     // A global load inside the streaming loop would have to be waited for with vmcnt(0),
     // i.e. drain every weight tile in flight, so everything is fetched here and parked in LDS.
     const int row_off = (MODE == MODE_VEC && a.x_last_row) ? n_rows - 1 : 0;
-    const bool pro_fast = (a.K >> 3) <= nthreads;
-    ProRegs<RM> pr;
+    // X rows in registers while the first weights are requested: one 16-byte chunk of every row per thread,
+    // or (K beyond 8 * threads) two chunks of up to half as many rows
+    constexpr int NS = (MODE == MODE_VEC) ? 2 : KG_MAX_ROWS;
+    const int pro_sets = ((a.K >> 3) <= nthreads) ? 1 : 2;
+    const bool pro_fast = (a.K >> 3) <= pro_sets * nthreads && M * pro_sets <= NS;
+    ProRegs<NS> pr;
     float ss[RM];                                                // this thread's share of sum(x^2) per row
 #pragma unroll
     for (int m = 0; m < RM; ++m) ss[m] = 0.f;
     if (MODE != MODE_MFMA_GX) {
-        if (pro_fast) prologue_load<PRO, RM, COH_LD>(a, pr, M, row_off, tid);
+        if (pro_fast && pro_sets == 1) prologue_load<PRO, NS, 1, COH_LD>(a, pr, M, row_off, tid, nthreads);
+        else if (pro_fast) prologue_load<PRO, NS, 2, COH_LD>(a, pr, M, row_off, tid, nthreads);
         else prologue_slow<DT, PRO, RM, COH_LD>(a, xs, xs_stride, ss, M, row_off, tid, nthreads);
     }
     unsigned side_raw[2] = {0u, 0u};
@@ -435,7 +449,10 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
             }
         }
     }
-    if (MODE != MODE_MFMA_GX && pro_fast) prologue_finish<DT, PRO, RM>(a, pr, xs, xs_stride, ss, M, tid);
+    if (MODE != MODE_MFMA_GX && pro_fast) {
+        if (pro_sets == 1) prologue_finish<DT, PRO, NS, RM, 1>(a, pr, xs, xs_stride, ss, M, tid, nthreads);
+        else prologue_finish<DT, PRO, NS, RM, 2>(a, pr, xs, xs_stride, ss, M, tid, nthreads);
+    }
     __syncthreads();
     KG_TSTAMP(a, 2);
 
