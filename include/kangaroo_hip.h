@@ -148,6 +148,9 @@ int kg_session_get(kg_session* s, const char* key);
  * evaluation/inference_kangaroo_MTBench.py:377-389).  Block counts never change results; wave counts set how K is split
  * inside a block and therefore the fp32 summation order.  Values must be >= 1.
  * kg_session_get reads the per-op keys and "persist" (0 / 1) back.
+ * "vanilla_gemv" (2: plain decoding, kg_generate mode 1, runs every layer and the head through the 1-row
+ * GEMV kernels — faster by a few per cent, but no longer the arithmetic of a verify row, so not the
+ * comparator of the token-identity tests; 1: off, the default).
  * "bench_layers": kg_bench_op cycles through this many layers' weights (all by default; 1 measures
  * the kernels on cache-warm weights). */
 int kg_session_set(kg_session* s, const char* key, int value);

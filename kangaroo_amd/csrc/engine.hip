@@ -68,6 +68,7 @@ struct kg_session {
     char *pf_h, *pf_xn, *pf_xq, *pf_ao, *pf_act;   // activations of a prefill pass (KG_GEMM_ROWS rows)
     float* pf_part;                    // K-range partial sums of the d-row prefill projections [4][KG_GEMM_ROWS][d]
     int gemm_prefill;                  // 1: prompts go through the 128-row GEMM passes
+    int vanilla_gemv;                  // 1: plain decoding runs every layer and the head through the 1-row GEMV kernels
     int bench_layers;                  // kg_bench_op cycles through this many layers' weights (1: cache-warm)
     unsigned long long* tlog;          // phase timeline of the last persistent launch (KG_PERSIST_TLOG=1), else null
     std::vector<int> prog_kinds[3];
@@ -187,6 +188,7 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     s->accept_top_p = 0.f; s->temperature = 1.f;
     s->gemm_prefill = s->v_transposed;           // the GEMM passes need the MFMA attention kernel
     s->bench_layers = s->sh.num_layers;
+    s->vanilla_gemv = 0;
     s->attn_teams = 1;
     s->attn_blocks = 16;                         // one chunk per block: long contexts need many CUs pulling K/V (one CU sustains only ~60 GB/s)
     s->round_graph = nullptr; s->round_graph_steps = -1; s->vanilla_graph = nullptr;
@@ -230,6 +232,7 @@ extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
     bool done = false;
     if (k == "attn_nsplit") { if (value > 32) return fail(-1, "nsplit <= 32"); s->attn_nsplit = value; done = true; }
     if (k == "gemm_prefill") { s->gemm_prefill = (value >= 2 && s->v_transposed) ? 1 : 0; done = true; }   // 1: off, 2: on
+    if (k == "vanilla_gemv") { s->vanilla_gemv = value >= 2 ? 1 : 0; done = true; }   // 1: off, 2: on
     if (k == "bench_layers") { s->bench_layers = value < s->sh.num_layers ? value : s->sh.num_layers; done = true; }
     if (k == "accept_top_k") { if (value > s->sh.vocab_size) return fail(-1, "accept_top_k <= vocab_size"); s->accept_top_k = value; done = true; }
     if (k == "attn_teams") { if (value > 2) return fail(-1, "attn_teams is 1 or 2"); s->attn_teams = value; done = true; }
@@ -290,6 +293,7 @@ extern "C" int kg_session_get(kg_session* s, const char* key) {
     if (k == "attn_teams") return s->attn_teams;
     if (k == "accept_top_k") return s->accept_top_k;
     if (k == "gemm_prefill") return s->gemm_prefill;
+    if (k == "vanilla_gemv") return s->vanilla_gemv;
     if (k == "persist") return s->persist;
     if (k == "prefill_rows") return s->prefill_rows;
     return -1;
@@ -648,7 +652,13 @@ static int enqueue_vanilla(kg_session* s, hipStream_t st) {
     // the step's state and input row were left by the previous step's kg_vanilla_end (kg_generate: by a
     // kg_vanilla_begin launch after the prefill)
     int nb = 0;
-    if (s->prog_n[1] > 0) {
+    if (s->vanilla_gemv) {
+        // not the comparator of the losslessness tests: the remaining layers in GEMV arithmetic differ from
+        // a verify row in summation order; this is the fastest plain decoding these kernels offer
+        for (int l = 0; l < sh.num_layers; ++l)
+            KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_shallow, 1, s->h, s->h, st));
+        KG_TRY(run_head(s, s->dyn_shallow, 1, s->h, 0, s->w.final_norm, nullptr, &nb, st));
+    } else if (s->prog_n[1] > 0) {
         for (int l = 0; l < sh.exit_layer; ++l)
             KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_shallow, 1, s->h, s->h, st));
         KG_TRY(run_program(s, 1, st));
