@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--spec-steps", type=int, default=6)
     ap.add_argument("--threshold", type=float, default=0.6)
     ap.add_argument("--recipe", default=f"{CAL_RECIPE[0]}:{CAL_RECIPE[1]}")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="storage / MFMA input type of weights, activations and caches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vanilla", action="store_true")
     a = ap.parse_args()
@@ -110,8 +111,9 @@ def main():
     shape = get_shape(a.model)
     L = DEFAULT_EXIT_LAYER.get(a.model, 2)
     ds, hs = [float(x) for x in a.recipe.split(":")]
-    base_sd, adapter_sd = synth_state_dicts(shape, L, seed=0, dtype=torch.float16, recipe=Recipe.agreeable(ds, hs), device=dev)
-    model = KangarooModel.from_state_dicts(shape, base_sd, adapter_sd, torch.float16, L, device=dev)
+    tdt = torch.float16 if a.dtype == "f16" else torch.bfloat16
+    base_sd, adapter_sd = synth_state_dicts(shape, L, seed=0, dtype=tdt, recipe=Recipe.agreeable(ds, hs), device=dev)
+    model = KangarooModel.from_state_dicts(shape, base_sd, adapter_sd, tdt, L, device=dev)
     eng = model.engine
 
     K, W = a.steps, a.warmup
@@ -216,8 +218,8 @@ def main():
     res = {
         "metric": "decode tokens/s at bsz=1 (Kangaroo, prefill included)", "value": total_tokens / t_job, "unit": "tokens/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * t_job / max(1, K), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"{a.model} shape fp16 Kangaroo exitlayer={L} steps={a.spec_steps} thr={a.threshold} greedy, "
+        "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"{a.model} shape {'fp16' if a.dtype == 'f16' else 'bf16'} Kangaroo exitlayer={L} steps={a.spec_steps} thr={a.threshold} greedy, "
                                f"Spec-Bench-shaped synthetic prompts, max_new_tokens={a.max_new_tokens}, random-init weights "
                                f"(deep_scale={ds}, head_scale={hs})",
                    "prompts_per_gpu": K, "parallelism": f"prompt-sharded x{world} (replicas, no collectives)"},
