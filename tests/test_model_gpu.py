@@ -315,6 +315,25 @@ def test_constructor_from_checkpoint_dirs_and_eval_harness(tmp_path):
     assert len(lines) == len(prompts) and set(lines[0]["choices"][0]) >= {"new_tokens", "wall_time", "idxs", "accept_lengths"}
 
 
+def test_vanilla_gemv_mode_agrees_up_to_near_ties():
+    """Plain decoding with every layer in the 1-row GEMV kernels (tuning key vanilla_gemv = 2): same model,
+    other summation order in the remaining layers, so the ids equal the standard comparator's or part on
+    an argmax near-tie."""
+    shape = get_shape("small")
+    base, adapter = synth_state_dicts(shape, 2, seed=41, dtype=torch.float16, recipe=Recipe.agreeable(0.3, 8.0))
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, 2)
+    ids = torch.randint(3, shape.vocab_size, (1, 14), generator=torch.Generator().manual_seed(41)).cuda()
+    std = vanilla_forward(ids, model, -1, 64)[0][0]
+    model.engine.set_tuning(vanilla_gemv=2)
+    assert model.engine.get_tuning("vanilla_gemv") == 1
+    gemv = vanilla_forward(ids, model, -1, 64)[0][0]
+    model.engine.set_tuning(vanilla_gemv=1)
+    assert len(gemv) == len(std)
+    if gemv != std:
+        explain_divergence(gemv, std, 14, oracle_model("small", base, adapter, 2))
+    assert vanilla_forward(ids, model, -1, 64)[0][0] == std
+
+
 def test_bf16_runs_and_is_lossless():
     shape = get_shape("small")
     base, adapter = synth_state_dicts(shape, 2, seed=21, dtype=torch.bfloat16, recipe=Recipe.agreeable(0.3, 8.0))
