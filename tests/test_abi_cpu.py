@@ -1,6 +1,7 @@
 """CPU-side checks: the C-ABI library loads and exports every symbol the header declares,
 host logic (packing, shapes, checkpoint formats, prompt sharding, harness metrics), and the
 product path fails loudly without a GPU instead of falling back to anything."""
+import json
 import os
 import re
 import subprocess
@@ -178,3 +179,26 @@ def test_prompt_sharding_two_ranks_gloo(tmp_path):
     assert j["tokens"] == float(sum(p.input_ids.shape[1] for p in ps))
     assert j["tmax"] == 2.0
     assert j["ids"][0] + j["ids"][1] == [p.question_id for p in ps] and len(j["ids"][0]) == 5
+
+
+def test_question_file_conversation_and_answer_file(tmp_path):
+    """Host-side pieces of the question-file evaluation loop (no GPU): Vicuna turn format, question
+    slicing, answer-file re-ordering."""
+    from kangaroo_amd.eval import VicunaConversation, load_questions, reorg_answer_file, VICUNA_SYSTEM
+    conv = VicunaConversation()
+    conv.append_message(conv.roles[0], "Hi")
+    conv.append_message(conv.roles[1], None)
+    assert conv.get_prompt() == VICUNA_SYSTEM + " USER: Hi ASSISTANT:"
+    conv.messages[-1][-1] = "Hello!"
+    conv.append_message(conv.roles[0], "Again")
+    conv.append_message(conv.roles[1], None)
+    assert conv.get_prompt() == VICUNA_SYSTEM + " USER: Hi ASSISTANT: Hello!</s>USER: Again ASSISTANT:"
+    qf = tmp_path / "question.jsonl"
+    qf.write_text("".join(json.dumps({"question_id": i, "category": "qa", "turns": [f"q{i}"]}) + "\n" for i in range(5)))
+    assert [q["question_id"] for q in load_questions(str(qf), 1, 4)] == [1, 2, 3]
+    assert len(load_questions(str(qf))) == 5
+    af = tmp_path / "answers.jsonl"
+    af.write_text("".join(json.dumps({"question_id": i, "v": v}) + "\n" for i, v in [(3, 0), (1, 0), (3, 1)]))
+    reorg_answer_file(str(af))
+    rows = [json.loads(l) for l in af.read_text().splitlines()]
+    assert [(r["question_id"], r["v"]) for r in rows] == [(1, 0), (3, 1)]

@@ -334,6 +334,54 @@ def test_vanilla_gemv_mode_agrees_up_to_near_ties():
     assert vanilla_forward(ids, model, -1, 64)[0][0] == std
 
 
+class _StubTokenizer:
+    """Hugging Face call surface over a toy vocabulary: a character maps to 3 + ord % (V - 3)."""
+    eos_token_id = 2
+    special_tokens_map = {"eos_token": "</s>"}
+
+    def __init__(self, vocab):
+        self.vocab = vocab
+
+    def __call__(self, texts, return_tensors="pt"):
+        import types
+        ids = torch.tensor([[3 + ord(ch) % (self.vocab - 3) for ch in texts[0][-40:]]])
+        return types.SimpleNamespace(input_ids=ids, to=lambda dev: types.SimpleNamespace(input_ids=ids.to(dev)))
+
+    def decode(self, ids, spaces_between_special_tokens=False):
+        return " ".join(str(int(i)) for i in ids)
+
+
+def test_question_file_eval_loop(tmp_path):
+    """Question JSONL in, answer JSONL out with the reference's fields (evaluation/eval.py:221-246), two turns
+    per question, Kangaroo and plain decoding giving the same answers."""
+    from kangaroo_amd.eval import run_eval as run_questions
+    z, meta, base, adapter = load_case(CASES[1])
+    L = meta["exit_layer"]
+    shape = get_shape(meta["shape"])
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, L)
+    tok = _StubTokenizer(shape.vocab_size)
+    qf = tmp_path / "question.jsonl"
+    qf.write_text("".join(json.dumps({"question_id": 80 + i, "category": "mt_bench", "turns": [f"first {i}", f"second {i}"]}) + "\n" for i in range(3)))
+    outs = {}
+    for name, fwd in (("kangaroo", lambda inp, m, t, n, **kw: kangaroo_forward(inp, m, t, n, EARLY_STOP_LAYER=L, **kw)),
+                      ("vanilla", lambda inp, m, t, n, **kw: vanilla_forward(inp, m, t, n))):
+        af = tmp_path / f"{name}.jsonl"
+        mean_accept = run_questions(model, tok, fwd, name, str(qf), None, None, str(af), 24)
+        rows = [json.loads(l) for l in open(af)]
+        assert [r["question_id"] for r in rows] == [80, 81, 82] and all(r["model_id"] == name for r in rows)
+        c = rows[0]["choices"][0]
+        assert set(c) == {"index", "turns", "idxs", "new_tokens", "wall_time", "accept_lengths"}
+        assert len(c["turns"]) == 2 and len(c["new_tokens"]) == 2 and sum(c["accept_lengths"]) == sum(c["new_tokens"])
+        assert mean_accept >= 1.0
+        outs[name] = [r["choices"][0]["turns"] for r in rows]
+    for a, b in zip(outs["kangaroo"], outs["vanilla"]):
+        # first turns see the same prompt: same ids up to the shorter, budget-bounded answer (the second
+        # turn's prompt contains the first answer, whose length differs between the two loops)
+        ta, tb = a[0].split(), b[0].split()
+        n = min(len(ta), len(tb))
+        assert n >= 24 - 1 - 6 and ta[:n] == tb[:n]
+
+
 def test_bf16_runs_and_is_lossless():
     shape = get_shape("small")
     base, adapter = synth_state_dicts(shape, 2, seed=21, dtype=torch.bfloat16, recipe=Recipe.agreeable(0.3, 8.0))
