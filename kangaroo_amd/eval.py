@@ -152,3 +152,39 @@ def run_eval(model, tokenizer, forward_func: Callable, model_id: str, question_f
     if world_size == 1:
         reorg_answer_file(answer_file)
     return mean_accept
+
+
+MT_BENCH_CATEGORIES = ("writing", "roleplay", "reasoning", "math", "coding", "extraction", "stem", "humanities")
+
+
+def _read_task(jsonl_file: str, task: str) -> List[Dict]:
+    rows = []
+    with open(jsonl_file, encoding="utf-8") as f:
+        for line in f:
+            if not line.strip():
+                continue
+            obj = json.loads(line)
+            if task == "overall" or (task == "mt_bench" and obj.get("category") in MT_BENCH_CATEGORIES) or obj.get("category") == task:
+                rows.append(obj)
+    return rows
+
+
+def speed(jsonl_file: str, jsonl_file_base: str, tokenizer=None, task: str = "overall") -> Dict[str, float]:
+    """The report of evaluation/speed.py:7-68 from two answer files: tokens/s = mean over questions of
+    sum(new_tokens) / sum(wall_time) of choice 0; the baseline's tokens are counted by re-tokenising its
+    answers (len(ids) - 1 per turn, :49-52) when a tokenizer is given, else taken from its `new_tokens`;
+    speed-up = ratio of the two means; mean accept length over all of the first file's accept lengths."""
+    speeds, accept = [], []
+    for row in _read_task(jsonl_file, task):
+        c = row["choices"][0]
+        speeds.append(sum(c["new_tokens"]) / sum(c["wall_time"]))
+        accept.extend(c["accept_lengths"])
+    speeds0 = []
+    for row in _read_task(jsonl_file_base, task):
+        c = row["choices"][0]
+        tokens = sum(len(tokenizer(t).input_ids) - 1 for t in c["turns"]) if tokenizer is not None else sum(c["new_tokens"])
+        speeds0.append(tokens / sum(c["wall_time"]))
+    tps = sum(speeds) / max(1, len(speeds))
+    tps0 = sum(speeds0) / max(1, len(speeds0))
+    return {"tokens_per_second": tps, "tokens_per_second_baseline": tps0, "speedup": tps / tps0 if tps0 else float("nan"),
+            "mean_accept": sum(accept) / max(1, len(accept)), "questions": float(len(speeds))}

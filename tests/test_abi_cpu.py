@@ -202,3 +202,16 @@ def test_question_file_conversation_and_answer_file(tmp_path):
     reorg_answer_file(str(af))
     rows = [json.loads(l) for l in af.read_text().splitlines()]
     assert [(r["question_id"], r["v"]) for r in rows] == [(1, 0), (3, 1)]
+
+
+def test_speed_report_from_answer_files(tmp_path):
+    from kangaroo_amd.eval import speed
+    def row(qid, cat, nt, wt, acc):
+        return json.dumps({"question_id": qid, "category": cat, "choices": [{"index": 0, "turns": ["a b c"], "idxs": [1], "new_tokens": nt, "wall_time": wt, "accept_lengths": acc}]}) + "\n"
+    k = tmp_path / "k.jsonl"; b = tmp_path / "b.jsonl"
+    k.write_text(row(1, "qa", [100, 50], [0.5, 0.25], [1, 2, 3]) + row(2, "math", [80], [0.2], [2, 2]))
+    b.write_text(row(1, "qa", [100, 50], [1.0, 0.5], [1]) + row(2, "math", [80], [0.8], [1]))
+    r = speed(str(k), str(b))
+    assert abs(r["tokens_per_second"] - (200 + 400) / 2) < 1e-9 and abs(r["tokens_per_second_baseline"] - (100 + 100) / 2) < 1e-9
+    assert abs(r["speedup"] - 3.0) < 1e-9 and abs(r["mean_accept"] - 2.0) < 1e-9
+    assert speed(str(k), str(b), task="qa")["questions"] == 1
