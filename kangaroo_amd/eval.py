@@ -188,3 +188,48 @@ def speed(jsonl_file: str, jsonl_file_base: str, tokenizer=None, task: str = "ov
     tps0 = sum(speeds0) / max(1, len(speeds0))
     return {"tokens_per_second": tps, "tokens_per_second_baseline": tps0, "speedup": tps / tps0 if tps0 else float("nan"),
             "mean_accept": sum(accept) / max(1, len(accept)), "questions": float(len(speeds))}
+
+
+def main(argv: Optional[Sequence[str]] = None) -> None:
+    """Command line of evaluation/inference_kangaroo.py:131-245 (same flags; `--question-file` and
+    `--baseline` added): three runs over the question file, answers to data/<bench>/<model-id>/<run>.jsonl."""
+    import argparse
+    import types
+    ap = argparse.ArgumentParser(description="Kangaroo question-file evaluation on MI355X")
+    ap.add_argument("--model-path", required=True)
+    ap.add_argument("--adapter-path", required=True)
+    ap.add_argument("--model-id", required=True)
+    ap.add_argument("--bench-name", default="mt_bench")
+    ap.add_argument("--question-file", default="data/question.jsonl")
+    ap.add_argument("--question-begin", type=int)
+    ap.add_argument("--question-end", type=int)
+    ap.add_argument("--max-new-tokens", type=int, default=1024)
+    ap.add_argument("--num-choices", type=int, default=1)
+    ap.add_argument("--threshold", type=float, default=0.4)
+    ap.add_argument("--exitlayer", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--dtype", default="float16", choices=["float16", "bfloat16"])
+    ap.add_argument("--runs", type=int, default=3)
+    ap.add_argument("--baseline", action="store_true", help="plain greedy decoding on the same kernels instead of Kangaroo")
+    a = ap.parse_args(argv)
+    from transformers import AutoTokenizer
+    from .inference import kangaroo_forward, vanilla_forward
+    from .kangaroo_model import KangarooModel
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    model = KangarooModel(a.model_path, a.adapter_path, types.SimpleNamespace(dtype=a.dtype), EARLY_STOP_LAYER=a.exitlayer)
+    tokenizer = AutoTokenizer.from_pretrained(a.model_path)
+    if a.baseline:
+        fwd, kw = (lambda inputs, m, t, n, **k: vanilla_forward(inputs, m, t, n)), {}
+    else:
+        fwd, kw = kangaroo_forward, dict(threshold=a.threshold, SPECULATIVE_DECODING_STEPS=a.steps, EARLY_STOP_LAYER=a.exitlayer)
+    for run in range(a.runs):
+        answer_file = f"data/{a.bench_name}/{a.model_id}/{run}.jsonl"
+        print(f"Output to {answer_file}")
+        mean_accept = run_eval(model, tokenizer, fwd, a.model_id, a.question_file, a.question_begin, a.question_end, answer_file,
+                               a.max_new_tokens, a.num_choices, rank=rank, world_size=world, **kw)
+        print("#Mean accepted tokens: ", mean_accept)
+
+
+if __name__ == "__main__":
+    main()

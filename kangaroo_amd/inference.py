@@ -30,7 +30,7 @@ def _rule_of(do_sample, hyper_k, hyper_p, temperature):
     "top_k" with hyper_k (inference_kangaroo_MTBench.py:377-389) or "top_p" with hyper_p and temperature
     (:356-374; temperature 0 means greedy there, :282-290).  The rules that draw random numbers
     ("typical", "typical_sampling") are not offered.  Returns engine.generate keyword arguments."""
-    if do_sample in (False, None, "greedy"):
+    if do_sample in (False, True, None, "greedy"):      # the loop of inference_kangaroo.py is greedy whatever the flag says (:15-129; its caller passes True, :239)
         return {}
     if do_sample == "top_k":
         if int(hyper_k) < 1:
