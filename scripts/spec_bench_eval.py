@@ -24,9 +24,14 @@ model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, L, r
 prompts = spec_bench_prompts(shape.vocab_size, a.prompts)
 fk = lambda ids, m, eos, n, **kw: kangaroo_forward(ids, m, eos, n, EARLY_STOP_LAYER=L, **kw)
 fv = lambda ids, m, eos, n, **kw: vanilla_forward(ids, m, eos, n)
-recs = run_eval(model, fk, prompts, a.max_new_tokens, -1, keep_ids=True)
-print("kangaroo done", flush=True)
-base_recs = run_eval(model, fv, prompts, a.max_new_tokens, -1, keep_ids=True)
+def run_chunks(f, tag):
+    out = []
+    for i in range(0, len(prompts), 8):          # a progress line per 8 prompts (a silent run counts as hung)
+        out += run_eval(model, f, prompts[i:i + 8], a.max_new_tokens, -1, warmup=1 if i == 0 else 0, keep_ids=True)
+        print(f"{tag}: {len(out)}/{len(prompts)} prompts", flush=True)
+    return out
+recs = run_chunks(fk, "kangaroo")
+base_recs = run_chunks(fv, "vanilla")
 identical = sum(int(r.output_ids[:min(len(r.output_ids), len(b.output_ids))] == b.output_ids[:min(len(r.output_ids), len(b.output_ids))]) for r, b in zip(recs, base_recs))
 report = {"model": a.model, "exit_layer": L, "prompts": len(prompts), "max_new_tokens": a.max_new_tokens,
           "identical_to_vanilla": f"{identical}/{len(prompts)}", "overall": speed_report(recs, base_recs), "groups": {}}
