@@ -54,25 +54,49 @@ def round_kv_bytes(shape, L, d, T):
     return passes * per_pos * T + ((d + 1) * L + d + (d + 1) * (shape.num_hidden_layers - L)) * per_pos
 
 
-def cpu_baseline(shape, L, base_sd_gpu, adapter_sd_gpu, steps, thr, budget_new=32, prompt_len=32):
-    """The oracle (CPU restatement of the reference loop, fp32 math on the same fp16
-    weights) timed on the host cores over one short prompt."""
+def cpu_baseline(shape, L, base_sd_gpu, adapter_sd_gpu, steps, thr, model, n_prompts=4, budget_new=32, prompt_len=32):
+    """The oracle (CPU restatement of the reference loop, fp32 math on the same 16-bit weights) timed on the
+    host cores over a bounded sample: n_prompts prompts of prompt_len tokens, budget_new new tokens each.
+    The same prompts then run on the device, and whatever differs first per prompt (a token, an accept or a
+    draft length) is traced by oracle/parity.py: the oracle is teacher-forced on the device's prefix and the
+    device's token and logits row must sit within 1e-2 of the row's max-abs (a 16-bit argmax near-tie)."""
     from oracle import kangaroo_oracle as ko
+    from oracle import parity
+    from kangaroo_amd.inference import kangaroo_forward
     t0 = time.time()
     base = {k: v.to("cpu") for k, v in base_sd_gpu.items()}
     adapter = {k: v.to("cpu") for k, v in adapter_sd_gpu.items()}
     om = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), base, adapter, L)
     del base, adapter
     setup = time.time() - t0
-    ids = torch.randint(3, shape.vocab_size, (1, prompt_len), generator=torch.Generator().manual_seed(7))
-    t0 = time.time()
-    out, new_tok, idx, accept = ko.kangaroo_forward(ids, om, -1, budget_new, EARLY_STOP_LAYER=L,
-                                                    SPECULATIVE_DECODING_STEPS=steps, threshold=thr)
-    dt = time.time() - t0
-    return {"value": new_tok / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 prompt of {prompt_len} tokens, {new_tok} new tokens in {dt:.1f} s (prefill included), fp32 math; "
+    tot_new, tot_dt, accepts, diffs, same_tokens, cmp_tokens = 0, 0.0, [], [], 0, 0
+    for i in range(n_prompts):
+        ids = torch.randint(3, shape.vocab_size, (1, prompt_len), generator=torch.Generator().manual_seed(7 + i))
+        tr = ko.Trace()
+        t0 = time.time()
+        ref = ko.kangaroo_forward(ids, om, -1, budget_new, EARLY_STOP_LAYER=L, SPECULATIVE_DECODING_STEPS=steps, threshold=thr,
+                                  trace=tr, keep_logits=True)
+        tot_dt += time.time() - t0
+        tot_new += ref[1]
+        accepts += ref[3]
+        # the same prompt on the device (untimed): token identity with the CPU path, or a traced near-tie
+        out, new_tok, idx, accept, st = kangaroo_forward(ids.cuda(), model, -1, budget_new, EARLY_STOP_LAYER=L,
+                                                         SPECULATIVE_DECODING_STEPS=steps, threshold=thr, return_stats=True)
+        rec = parity.first_difference(out[0], accept, st.draft_lengths, ref[0][0], ref[3], tr.draft_lengths, prompt_len, om,
+                                      tr.p_max, tr.draft_logits, thr,
+                                      dev_logits_row=lambda pre: model.base_model(torch.tensor([pre]).cuda(), logits_rows="last").logits[0, -1])
+        rec["prompt_seed"] = 7 + i
+        diffs.append(rec)
+        n = min(len(out[0]), len(ref[0][0]))
+        same_tokens += next((j for j in range(n) if out[0][j] != ref[0][0][j]), n) - prompt_len
+        cmp_tokens += n - prompt_len
+    return {"value": tot_new / tot_dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_prompts} prompts of {prompt_len} tokens, {tot_new} new tokens in {tot_dt:.1f} s (prefill included), fp32 math; "
                       f"weights upcast in {setup:.0f} s (untimed)",
-            "mean_accept": sum(accept) / len(accept)}, out[0], ids
+            "mean_accept": sum(accepts) / len(accepts),
+            "identical_tokens_vs_gpu": f"{same_tokens}/{cmp_tokens} new tokens before the first difference, summed over the prompts",
+            "first_difference": diffs,
+            "all_differences_within_tol": all(d["kind"] == "none" or d["within_tol"] for d in diffs)}
 
 
 def main():
@@ -87,12 +111,16 @@ def main():
     ap.add_argument("--recipe", default=f"{CAL_RECIPE[0]}:{CAL_RECIPE[1]}")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="storage / MFMA input type of weights, activations and caches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-prompts", type=int, default=4, help="prompts of the bounded CPU-baseline sample (32 tokens in, 32 out each)")
     ap.add_argument("--no-vanilla", action="store_true")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE is {world}: for N > 1 launch one rank per GPU with "
+                 f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...`")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -233,14 +261,8 @@ def main():
         "roofline": roofline, "kernels": per_kernel,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        del model
-        cb, cpu_ids, ids = cpu_baseline(shape, L, base_sd, adapter_sd, a.spec_steps, a.threshold)
-        # same prompt on the device: token identity with the CPU path
-        dev_ids, _ = eng.generate(ids[0], 32, mode="kangaroo", **kw)
-        n = min(len(dev_ids), len(cpu_ids))
-        same = next((i for i in range(n) if dev_ids[i] != cpu_ids[i]), n)
-        cb["identical_tokens_vs_gpu"] = f"{same - ids.shape[1]}/{n - ids.shape[1]} new tokens before the first difference"
-        res["cpu_baseline"] = cb
+        res["cpu_baseline"] = cpu_baseline(shape, L, base_sd, adapter_sd, a.spec_steps, a.threshold, model,
+                                           n_prompts=a.cpu_prompts)
     elif rank == 0:
         res["cpu_baseline"] = None
     if rank == 0:

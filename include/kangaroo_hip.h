@@ -5,7 +5,8 @@
  * point below names the reference code it stands in for.  All pointers marked "device"
  * are HIP device pointers owned by the caller (PyTorch allocates them); the library
  * never frees caller memory.  Every function returns 0 on success and a negative code
- * on failure (-1 bad argument, -2 HIP error, -3 does not fit on chip);
+ * on failure (-1 bad argument, -2 HIP error, -3 does not fit on chip, -4 an opt-in persistent pass
+ * gave up at a grid barrier and was switched off for the session: call again);
  * kg_last_error() gives the text.  Nothing throws.  `stream` is a hipStream_t passed
  * as void* (torch.cuda.current_stream().cuda_stream).
  *
@@ -94,11 +95,16 @@ const char* kg_last_error(void);
  *   epilogue 0: out = y; 1: out = resid + y (adapter.py:304); 3: out = silu(y_gate) * y_up
  *            (adapter.py:242, rows interleaved as wgu)
  * n_rows == 1 runs the wave-reduced GEMV, 2..16 the MFMA decode kernel, 17..128 the prefill GEMM
- * kernel (the base model's prompt pass, evaluation/inference_kangaroo.py:30; nblocks / nwaves unused). */
+ * kernel (the base model's prompt pass, evaluation/inference_kangaroo.py:30; nblocks / nwaves unused;
+ * with prologue 1 the rows are normalised into the scratch buffer first, once per pass).
+ * The RMSNorm keeps the reference's rounding points: x * rsqrt(mean x^2 + eps) is rounded to the
+ * model dtype before the product with norm_w is rounded again (adapter.py:257-259). */
 int kg_linear(int dtype, const void* w_packed, int N, int K, const void* x, int n_rows,
               int prologue, const void* norm_w, float eps,
               int epilogue, const void* resid, void* out, int out_stride,
-              void* scratch /* device, >= 256 B */, int nblocks, int nwaves, void* stream);
+              void* scratch /* device, >= kg_linear_scratch_bytes(n_rows, K) */, int nblocks, int nwaves, void* stream);
+/* 256 B, plus room for the normalised rows of a pass of more than 16 rows */
+size_t kg_linear_scratch_bytes(int n_rows, int K);
 
 /* Fused RMSNorm + QKV projection + RoPE + in-place KV append for n_rows (<= 128) rows at
  * positions pos0.. (adapter.py:170-189 with the cache growing by torch.cat there).
@@ -109,7 +115,7 @@ int kg_qkv_rope_append(int dtype, const void* wqkv_packed, int d, int n_heads, i
                        const void* x, int n_rows, int pos0, const void* norm_w, float eps,
                        const float* rope_cos, const float* rope_sin,
                        void* q_out, void* k_cache, void* v_cache, int t_max, int v_transposed,
-                       void* scratch, int nblocks, int nwaves, void* stream);
+                       void* scratch /* device, >= kg_linear_scratch_bytes(n_rows, d) */, int nblocks, int nwaves, void* stream);
 
 /* Causal attention of n_rows query rows (<= 16; <= 128 with v_transposed) at positions pos0..
  * over the cache rows [0, pos0 + n_rows) (adapter.py:191-221; the mask of :38-67 is the causal bound). */
@@ -125,6 +131,27 @@ int kg_head(int dtype, const void* w_packed, int vocab, int d, const void* x, in
             void* logits_out, int* argmax_out, float* pmax_out,
             void* scratch /* device, kg_head_scratch_bytes() */, int nblocks, int nwaves, void* stream);
 size_t kg_head_scratch_bytes(int vocab);
+
+/* Accept / reject of one verify round on its own (evaluation/inference_kangaroo.py:92-104 and the
+ * cache-length rollback of :108-119; rules 1 and 2: evaluation/inference_kangaroo_MTBench.py:377-389 and
+ * :356-374).  Runs the accept kernel of the decode loop (and its rank / nucleus kernels) on a loop state
+ * laid out in `scratch`.  logits: device, [q, vocab] stored 16-bit verify logits of rows start_index ..
+ * start_index+q-1 (q <= 15); drafted_host: q-1 tokens drafted for positions start_index+1 ..; rule 0 greedy,
+ * 1 top-k, 2 top-p on softmax(logits / temperature); steps / max_infer: the loop bound of :46 for out[5].
+ * out_host[8] = accept length, token written at the new start index, eos stop flag, new start index,
+ * adapter cache length after the rollback, next-round-runs flag, drafted count, rounds done. */
+int kg_accept(int dtype, const void* logits, int vocab, int q, const int32_t* drafted_host, int start_index,
+              int eos_token_id, int rule, int top_k, float top_p, float temperature, int steps, int max_infer,
+              int adapter_len, int32_t* out_host, void* scratch /* device, kg_control_scratch_bytes() */, void* stream);
+/* Control of one draft step on its own (evaluation/inference_kangaroo.py:55-61 adapter rows, :79-83 token and
+ * confidence, :74 the second early exit as it will apply to the next step).  logits: device, [1, vocab] draft
+ * logits of this step, or NULL to stop after the adapter-row decision.  out_host[8] = adapter rows of the step
+ * (2 = the missing-row patch), their first position, drafted token, float bits of the confidence, end_index
+ * after the step, next-step-drafts flag, adapter cache length, rows of the coming verify pass. */
+int kg_draft_step(int dtype, const void* logits, int vocab, int step, int steps, double threshold,
+                  int start_index, int end_index, int adapter_len, int32_t* out_host,
+                  void* scratch /* device, kg_control_scratch_bytes() */, void* stream);
+size_t kg_control_scratch_bytes(void);
 
 /* ---- model-level entry points ---------------------------------------------------- */
 
@@ -167,7 +194,8 @@ float kg_session_getf(kg_session* s, const char* key);
  * [t_max, d], "head_tok" int32[16], "head_pmax" float[16]); NULL for an unknown name. */
 void* kg_session_ptr(kg_session* s, const char* name);
 
-/* Copy token ids into the session's device token buffer at [pos0, pos0 + n). */
+/* Copy token ids into the session's device token buffer at [pos0, pos0 + n); ids outside
+ * [0, vocab_size) are refused with -1. */
 int kg_set_tokens(kg_session* s, const int32_t* tokens_host, int pos0, int n, void* stream);
 
 /* Layers [layer_begin, layer_end) of the base model on n_rows <= 16 rows at positions
@@ -188,7 +216,9 @@ int kg_head_logits(kg_session* s, const void* x, int n_rows, void* logits_out, i
  * reject and cache rollback run on the device.  mode 0 = Kangaroo, 1 = plain greedy
  * decoding on the same kernels (the comparator, inference_baseline.py:14-25).
  * out_tokens_host receives n_tokens ids; accept_log_host (may be NULL) receives per
- * round (accept_length, drafted) pairs.  Synchronises `stream` before returning. */
+ * round (accept_length, drafted) pairs.  The work runs on a stream the session owns, ordered after
+ * everything queued on `stream` at the time of the call; the call returns after that work has finished.
+ * Token ids outside [0, vocab_size) are refused with -1. */
 int kg_generate(kg_session* s, int mode, const int32_t* prompt_host, int context_length, int max_new_tokens,
                 int max_length, int steps, double threshold, int eos_token_id,
                 int32_t* out_tokens_host, int32_t* accept_log_host, int accept_log_capacity,

@@ -48,11 +48,15 @@ SYMBOLS = {
     "kg_version": (_I, []),
     "kg_last_error": (C.c_char_p, []),
     "kg_linear": (_I, [_I, _VP, _I, _I, _VP, _I, _I, _VP, _F, _I, _VP, _VP, _I, _VP, _I, _I, _VP]),
+    "kg_linear_scratch_bytes": (_SZ, [_I, _I]),
     "kg_qkv_rope_append": (_I, [_I, _VP, _I, _I, _I, _I, _VP, _I, _I, _VP, _F, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _I, _I, _VP]),
     "kg_attention": (_I, [_I, _VP, _I, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "kg_attention_scratch_bytes": (_SZ, [_I, _I, _I]),
     "kg_head": (_I, [_I, _VP, _I, _I, _VP, _I, _I, _VP, _F, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "kg_head_scratch_bytes": (_SZ, [_I]),
+    "kg_accept": (_I, [_I, _VP, _I, _I, C.POINTER(C.c_int32), _I, _I, _I, _I, _F, _F, _I, _I, _I, C.POINTER(C.c_int32), _VP, _VP]),
+    "kg_draft_step": (_I, [_I, _VP, _I, _I, _I, _D, _I, _I, _I, C.POINTER(C.c_int32), _VP, _VP]),
+    "kg_control_scratch_bytes": (_SZ, []),
     "kg_workspace_bytes": (_SZ, [C.POINTER(KgShape), _I]),
     "kg_session_create": (_I, [C.POINTER(KgShape), C.POINTER(KgWeights), C.POINTER(KgBuffers), C.POINTER(_VP)]),
     "kg_session_destroy": (_I, [_VP]),

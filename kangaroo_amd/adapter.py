@@ -13,6 +13,7 @@ from typing import Optional
 
 import torch
 
+from .earlyexit import _check_positions
 from .engine import KangarooEngine
 
 
@@ -46,9 +47,10 @@ class AdapterModel:
         past = past_key_values[0][0].shape[2] if past_key_values is not None else 0
         if past + q_len > e.max_length:
             raise ValueError("sequence exceeds the cache")
+        _check_positions(position_ids, past, q_len)
         x = inputs_embeds[0]
         out = torch.empty((q_len, d), dtype=e.dtype, device=e.device)
-        C = 16 if 16 * (2 * d + 32) <= 160 * 1024 - 16 * 1024 else 8
+        C = e.get_tuning("prefill_rows")
         for c0 in range(0, q_len, C):
             n = min(C, q_len - c0)
             out[c0:c0 + n] = e.adapter_forward(x[c0:c0 + n], past + c0, n)

@@ -454,6 +454,44 @@ __global__ void kg_vanilla_end_kernel(KgLoopBufs b, const float* head_part, int 
     }
 }
 
+// Per-slice softmax records of stored logit rows, in the layout the lm_head kernel leaves them in
+// ([row][stride][4] = max, sum exp(l - max), argmax bits, -): block (b, m) covers the vocabulary slice
+// [b * per, (b + 1) * per) of row m.  Used by the kernel-level control entry points, which start from logits.
+template <int DT>
+__global__ void kg_logit_records_kernel(const unsigned short* logits, int vocab, int per, float* head_part, int stride) {
+    typedef KgT<DT> T;
+    __shared__ float s_mx[4], s_sum[4]; __shared__ int s_idx[4];
+    const int b = blockIdx.x, m = blockIdx.y;
+    const unsigned short* row = logits + (size_t)m * vocab;
+    const int v0 = b * per, v1 = min(vocab, v0 + per);
+    HeadRec r; r.mx = -INFINITY; r.sum = 0.f; r.idx = 0x7fffffff;
+    for (int v = v0 + threadIdx.x; v < v1; v += blockDim.x) {
+        HeadRec o; o.mx = T::to_f(row[v]); o.sum = 1.f; o.idx = v;
+        rec_merge(r, o);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        HeadRec t; t.mx = __shfl_xor(r.mx, o, 64); t.sum = __shfl_xor(r.sum, o, 64); t.idx = __shfl_xor(r.idx, o, 64);
+        rec_merge(r, t);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_mx[wave] = r.mx; s_sum[wave] = r.sum; s_idx[wave] = r.idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        HeadRec f; f.mx = s_mx[0]; f.sum = s_sum[0]; f.idx = s_idx[0];
+        for (int w = 1; w < 4; ++w) { HeadRec t; t.mx = s_mx[w]; t.sum = s_sum[w]; t.idx = s_idx[w]; rec_merge(f, t); }
+        float* hp = head_part + ((size_t)m * stride + b) * 4;
+        hp[0] = f.mx; hp[1] = f.sum; hp[2] = __int_as_float(f.idx); hp[3] = 0.f;
+    }
+}
+int kg_launch_logit_records(const void* logits, int vocab, int rows, int nblocks, float* head_part, int stride, int dtype, hipStream_t st) {
+    if (rows < 1 || rows > KG_MAX_ROWS || nblocks < 1 || nblocks > stride) return -1;
+    const int per = (vocab + nblocks - 1) / nblocks;
+    if (dtype == KG_F16) hipLaunchKernelGGL(kg_logit_records_kernel<KG_F16>, dim3(nblocks, rows), dim3(256), 0, st, (const unsigned short*)logits, vocab, per, head_part, stride);
+    else hipLaunchKernelGGL(kg_logit_records_kernel<KG_BF16>, dim3(nblocks, rows), dim3(256), 0, st, (const unsigned short*)logits, vocab, per, head_part, stride);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 #define KG_L1(k, ...) do { hipLaunchKernelGGL(k, dim3(1), dim3(256), 0, st, __VA_ARGS__); return hipGetLastError() == hipSuccess ? 0 : -2; } while (0)
 int kg_launch_round_begin(const KgLoopBufs& b, hipStream_t st) { KG_L1(kg_round_begin_kernel, b); }
 int kg_launch_step_mid(const KgLoopBufs& b, int step, hipStream_t st) { KG_L1(kg_step_mid_kernel, b, step); }

@@ -87,10 +87,13 @@ struct Carver {
 };
 
 static int prefill_rows_for(const kg_shape* sh) {
-    // X rows of one chunk must fit LDS beside the partial-sum slots (see kg_linear_smem)
-    size_t per_row = (size_t)sh->hidden_size * 2 + 32;
-    size_t avail = 160 * 1024 - 2 * 8 * 256 * 4;
-    return (16 * per_row <= avail) ? 16 : 8;
+    // X rows of one chunk must fit LDS beside the partial-sum slots and the largest staged epilogue input
+    // of a pass with an RMSNorm prologue (the RoPE rows of the qkv launch), exactly as kg_launch_linear adds them up
+    for (int rows = 16; rows > 1; rows >>= 1) {
+        const size_t side = ((size_t)rows * sh->head_dim * 4 + 255) / 256 * 256 + 512;
+        if (side + kg_linear_smem(1, rows, sh->hidden_size, 8) <= (size_t)160 * 1024) return rows;
+    }
+    return 1;
 }
 
 static void carve(kg_session* s, Carver& c, const kg_shape* sh, int t_max) {
@@ -418,6 +421,8 @@ static int run_program(kg_session* s, int which, hipStream_t st);
 extern "C" int kg_set_tokens(kg_session* s, const int32_t* tokens_host, int pos0, int n, void* stream) {
     g_err.clear();
     if (!s || !tokens_host || pos0 < 0 || n < 0 || pos0 + n > s->buf.t_max) return fail(-1, "bad token range");
+    for (int i = 0; i < n; ++i)
+        if (tokens_host[i] < 0 || tokens_host[i] >= s->sh.vocab_size) return fail(-1, "token id out of range");
     KG_CHECK_HIP(hipMemcpyAsync(s->tokens + pos0, tokens_host, (size_t)n * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
     return 0;
 }
@@ -781,6 +786,8 @@ extern "C" int kg_generate(kg_session* s, int mode, const int32_t* prompt_host, 
     if (context_length < 1 || max_length > s->buf.t_max || context_length >= max_length) return fail(-1, "context_length / max_length out of range");
     if (mode == 0 && (steps < 0 || steps + 1 > KG_MAX_ROWS - 1)) return fail(-1, "steps out of range");
     if (max_new_tokens < 1) return fail(-1, "max_new_tokens must be >= 1");
+    for (int i = 0; i < context_length; ++i)
+        if (prompt_host[i] < 0 || prompt_host[i] >= s->sh.vocab_size) return fail(-1, "token id out of range");
     hipStream_t st = s->own_stream;
     // order after whatever the caller queued on its stream
     KG_CHECK_HIP(hipEventRecord(s->ev_in, (hipStream_t)stream));
@@ -981,11 +988,21 @@ extern "C" int kg_linear(int dtype, const void* w_packed, int N, int K, const vo
     KG_TRY(kg_launch_set_dyn(dyn, 1, n_rows, 0, st));
     KgLinArgs a = lin_base(dyn, w_packed, N, K, x, K);
     a.norm_w = norm_w; a.eps = eps; a.out = out; a.out_stride = out_stride; a.resid = resid; a.resid_stride = out_stride;
+    if (n_rows > KG_MAX_ROWS && prologue == PRO_RMSNORM) {
+        // prefill-sized passes normalise their rows once, into the scratch buffer (kg_linear_scratch_bytes)
+        void* xn = (char*)scratch + 256;
+        KG_TRY(kg_launch_rmsnorm(dyn, x, K, norm_w, eps, K, xn, K, dtype, st));
+        a.x = xn; prologue = PRO_NONE;
+    }
     int rc = (n_rows > KG_MAX_ROWS) ? kg_launch_gemm(a, dtype, prologue, epilogue, st)       // prefill-sized pass
                                     : kg_launch_linear(a, dtype, n_rows, prologue, epilogue, nblocks > 0 ? nblocks : g_ncu * 2, nwaves > 0 ? nwaves : 8, st);
     if (rc == -3) return fail(-3, "rows x K exceed LDS");
     if (rc) return fail(rc, "kg_launch_linear failed");
     return 0;
+}
+
+extern "C" size_t kg_linear_scratch_bytes(int n_rows, int K) {
+    return 256 + (n_rows > KG_MAX_ROWS ? (size_t)n_rows * K * 2 : 0);
 }
 
 extern "C" int kg_qkv_rope_append(int dtype, const void* wqkv_packed, int d, int n_heads, int n_kv_heads, int head_dim,
@@ -1004,7 +1021,12 @@ extern "C" int kg_qkv_rope_append(int dtype, const void* wqkv_packed, int d, int
     KgLinArgs a = lin_base(dyn, wqkv_packed, qd + 2 * kvd, d, x, d);
     a.norm_w = norm_w; a.eps = eps; a.q_out = q_out; a.k_cache = k_cache; a.v_cache = v_cache;
     a.rope_cos = rope_cos; a.rope_sin = rope_sin; a.head_dim = head_dim; a.q_dim = qd; a.kv_dim = kvd; a.t_max = t_max; a.v_transposed = v_transposed ? 1 : 0;
-    int rc = (n_rows > KG_MAX_ROWS) ? kg_launch_gemm(a, dtype, PRO_RMSNORM, EPI_ROPE_KV, st)
+    if (n_rows > KG_MAX_ROWS) {
+        void* xn = (char*)scratch + 256;
+        KG_TRY(kg_launch_rmsnorm(dyn, x, d, norm_w, eps, d, xn, d, dtype, st));
+        a.x = xn;
+    }
+    int rc = (n_rows > KG_MAX_ROWS) ? kg_launch_gemm(a, dtype, PRO_NONE, EPI_ROPE_KV, st)
                                     : kg_launch_linear(a, dtype, n_rows, PRO_RMSNORM, EPI_ROPE_KV, nblocks > 0 ? nblocks : g_ncu * 2, nwaves > 0 ? nwaves : 8, st);
     if (rc) return fail(rc, "kg_launch_linear failed");
     return 0;
@@ -1067,3 +1089,131 @@ extern "C" int kg_head(int dtype, const void* w_packed, int vocab, int d, const 
     KG_TRY(kg_launch_head_finalize(dyn, a.head_part, a.head_part_stride, nb, n_rows, argmax_out, pmax_out, st));
     return 0;
 }
+
+// ---------------------------------------------------------------------------------
+// control kernels of the loop as entry points of their own: a throw-away loop state is laid out in the
+// caller's scratch buffer and the SAME kernels the round graph replays run on it
+// ---------------------------------------------------------------------------------
+namespace {
+struct CtlScratch {
+    int* state; int* tokens; KgDyn* dyn; int* head_tok; float* head_pmax; int* rank; float* head_part; int stride; int tok_cap;
+};
+const int KG_CTL_TOKENS = 4096;          // token slots of the scratch state
+const int KG_CTL_RECORDS = 256;          // head records per row
+size_t ctl_carve(CtlScratch* c, void* base) {
+    Carver cv{(char*)base, 0};
+    int* state = cv.take<int>(KS_HDR + 64);
+    int* tokens = cv.take<int>(KG_CTL_TOKENS);
+    KgDyn* dyn = cv.take<KgDyn>(3);
+    int* head_tok = cv.take<int>(KG_MAX_ROWS);
+    float* head_pmax = cv.take<float>(KG_MAX_ROWS);
+    int* rank = cv.take<int>(KG_MAX_ROWS + KG_MAX_ROWS * KG_MAX_ROWS);
+    float* head_part = cv.take<float>((size_t)KG_MAX_ROWS * KG_CTL_RECORDS * 4);
+    if (c) { c->state = state; c->tokens = tokens; c->dyn = dyn; c->head_tok = head_tok; c->head_pmax = head_pmax; c->rank = rank;
+             c->head_part = head_part; c->stride = KG_CTL_RECORDS; c->tok_cap = KG_CTL_TOKENS; }
+    return align_up(cv.off, 256);
+}
+KgLoopBufs ctl_bufs(const CtlScratch& c) {
+    KgLoopBufs b;
+    memset(&b, 0, sizeof(b));
+    b.state = c.state; b.tokens = c.tokens;
+    b.dyn_shallow = c.dyn; b.dyn_adapter = c.dyn + 1; b.dyn_verify = c.dyn + 2;
+    b.head_tok = c.head_tok; b.head_pmax = c.head_pmax;
+    b.d = 0; b.elt = 2;                  // no hidden rows: the kernels' row copies and embedding gathers move nothing
+    b.exited = c.state; b.prev_exit = c.state; b.adapter_in = c.state; b.embed = c.state; b.h = c.state;
+    return b;
+}
+}  // namespace
+
+extern "C" size_t kg_control_scratch_bytes(void) { return ctl_carve(nullptr, nullptr); }
+
+extern "C" int kg_accept(int dtype, const void* logits, int vocab, int q, const int32_t* drafted_host, int start_index,
+                         int eos_token_id, int rule, int top_k, float top_p, float temperature, int steps, int max_infer,
+                         int adapter_len, int32_t* out_host, void* scratch, void* stream) {
+    g_err.clear();
+    kg_init_once();
+    if (!logits || !out_host || !scratch || (q > 1 && !drafted_host)) return fail(-1, "null argument");
+    if (dtype != KG_F16 && dtype != KG_BF16) return fail(-1, "dtype");
+    if (q < 1 || q > KG_MAX_ROWS - 1 || vocab < 1) return fail(-1, "q must be in [1, 15]");
+    if (start_index < 0 || start_index + q + 1 > KG_CTL_TOKENS) return fail(-1, "start_index out of range for the scratch state");
+    if (rule < 0 || rule > 2 || (rule == 1 && (top_k < 2 || top_k > vocab)) || (rule == 2 && (!(top_p > 0.f && top_p <= 1.f) || !(temperature > 0.f))))
+        return fail(-1, "rule: 0 greedy, 1 top-k (2 <= k <= vocab), 2 top-p (0 < p <= 1, temperature > 0)");
+    hipStream_t st = (hipStream_t)stream;
+    CtlScratch c;
+    ctl_carve(&c, scratch);
+    KgLoopBufs b = ctl_bufs(c);
+    int hs[KS_HDR];
+    memset(hs, 0, sizeof(hs));
+    hs[KS_START] = start_index; hs[KS_END] = start_index + q; hs[KS_ADAPTER_LEN] = adapter_len; hs[KS_ALIVE] = 1;
+    hs[KS_MAX_INFER] = max_infer; hs[KS_STEPS] = steps; hs[KS_EOS] = eos_token_id;
+    KG_CHECK_HIP(hipMemcpyAsync(c.state, hs, sizeof(hs), hipMemcpyHostToDevice, st));
+    if (q > 1) KG_CHECK_HIP(hipMemcpyAsync(c.tokens + start_index + 1, drafted_host, (size_t)(q - 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    const int G = (vocab + 15) / 16, nb = G < KG_CTL_RECORDS ? G : KG_CTL_RECORDS;
+    KG_TRY(kg_launch_logit_records(logits, vocab, q, nb, c.head_part, c.stride, dtype, st));
+    if (rule == 2) KG_TRY(kg_launch_topp_member(b, logits, vocab, temperature, top_p, c.rank + KG_MAX_ROWS, dtype, st));
+    else if (rule == 1) KG_TRY(kg_launch_topk_rank(b, logits, vocab, c.rank, dtype, st));
+    KG_TRY(kg_launch_accept(b, c.head_part, c.stride, nb, c.rank, rule == 2 ? 0 : (rule == 1 ? top_k : 1), st));
+    int hs2[KS_HDR + 2];
+    KG_CHECK_HIP(hipMemcpyAsync(hs2, c.state, sizeof(hs2), hipMemcpyDeviceToHost, st));
+    int tok = 0;
+    KG_CHECK_HIP(hipStreamSynchronize(st));
+    const int snew = hs2[KS_START];
+    KG_CHECK_HIP(hipMemcpy(&tok, c.tokens + snew, sizeof(int), hipMemcpyDeviceToHost));
+    out_host[0] = hs2[KS_HDR];           // accept length (:104)
+    out_host[1] = tok;                   // token written at the new start index (:98)
+    out_host[2] = hs2[KS_STOP];          // eos produced (:100)
+    out_host[3] = snew;                  // new start index (:99)
+    out_host[4] = hs2[KS_ADAPTER_LEN];   // adapter cache length after the rollback (:114-118)
+    out_host[5] = hs2[KS_ALIVE];         // the next round runs (:46, :123)
+    out_host[6] = hs2[KS_HDR + 1];       // drafted tokens of the round
+    out_host[7] = hs2[KS_ROUND];
+    return 0;
+}
+
+extern "C" int kg_draft_step(int dtype, const void* logits, int vocab, int step, int steps, double threshold,
+                             int start_index, int end_index, int adapter_len, int32_t* out_host, void* scratch, void* stream) {
+    g_err.clear();
+    kg_init_once();
+    if (!out_host || !scratch) return fail(-1, "null argument");
+    if (dtype != KG_F16 && dtype != KG_BF16) return fail(-1, "dtype");
+    if (step < 0 || step >= steps || steps > KG_MAX_ROWS - 2) return fail(-1, "step must be in [0, steps)");
+    if (start_index < 1 || end_index <= start_index || end_index + 1 >= KG_CTL_TOKENS) return fail(-1, "indices out of range for the scratch state");
+    hipStream_t st = (hipStream_t)stream;
+    CtlScratch c;
+    ctl_carve(&c, scratch);
+    KgLoopBufs b = ctl_bufs(c);
+    int hs[KS_HDR];
+    memset(hs, 0, sizeof(hs));
+    hs[KS_START] = start_index; hs[KS_END] = end_index; hs[KS_ADAPTER_LEN] = adapter_len; hs[KS_ALIVE] = 1; hs[KS_DRAFT_ON] = 1;
+    hs[KS_STEPS] = steps; hs[KS_DRAFTED] = end_index - start_index - 1;
+    unsigned long long tb; memcpy(&tb, &threshold, 8);
+    hs[KS_THRESH_LO] = (int)(unsigned)(tb & 0xffffffffu); hs[KS_THRESH_HI] = (int)(unsigned)(tb >> 32);
+    KG_CHECK_HIP(hipMemcpyAsync(c.state, hs, sizeof(hs), hipMemcpyHostToDevice, st));
+    KG_CHECK_HIP(hipMemsetAsync(c.dyn, 0, 3 * sizeof(KgDyn), st));
+    // adapter rows of the step (:55-61): only step 0 can find the adapter cache one row short
+    KG_TRY(kg_launch_step_mid(b, step, st));
+    KgDyn dyn_mid;
+    KG_CHECK_HIP(hipMemcpyAsync(&dyn_mid, c.dyn + 1, sizeof(KgDyn), hipMemcpyDeviceToHost, st));
+    int nb = 0;
+    if (logits) {
+        const int G = (vocab + 15) / 16;
+        nb = G < KG_CTL_RECORDS ? G : KG_CTL_RECORDS;
+        KG_TRY(kg_launch_logit_records(logits, vocab, 1, nb, c.head_part, c.stride, dtype, st));
+        KG_TRY(kg_launch_step_end(b, step, c.head_part, nb, st));
+    }
+    int hs2[KS_HDR]; KgDyn dyn[3]; int tok = -1;
+    KG_CHECK_HIP(hipMemcpyAsync(hs2, c.state, sizeof(hs2), hipMemcpyDeviceToHost, st));
+    KG_CHECK_HIP(hipMemcpyAsync(dyn, c.dyn, sizeof(dyn), hipMemcpyDeviceToHost, st));
+    KG_CHECK_HIP(hipMemcpyAsync(&tok, c.tokens + end_index, sizeof(int), hipMemcpyDeviceToHost, st));
+    KG_CHECK_HIP(hipStreamSynchronize(st));
+    out_host[0] = dyn_mid.n_rows;        // adapter rows of this step (2: the missing-row patch)
+    out_host[1] = dyn_mid.pos[0];        // their first position
+    out_host[2] = logits ? tok : -1;     // drafted token (:80)
+    out_host[3] = hs2[KS_SCORE];         // float bits of the confidence (:83)
+    out_host[4] = hs2[KS_END];           // end_index after the step (:82)
+    out_host[5] = hs2[KS_DRAFT_ON];      // the next step's adapter + head run (:74)
+    out_host[6] = hs2[KS_ADAPTER_LEN];
+    out_host[7] = dyn[2].n_rows;         // rows the verify pass will carry
+    return 0;
+}
+

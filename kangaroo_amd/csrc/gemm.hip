@@ -8,8 +8,8 @@
 // walks all of K: per k-batch of 4 tiles it holds the A fragments in registers (a ring of four
 // batches, three in flight) and multiplies them with eight 16-row column blocks of X^T from LDS.  X^T is
 // staged batch by batch (128 rows x 128 k, double-buffered, XOR-swizzled) by four extra LOADER waves
-// of the block; RMSNorm's gamma can be applied while staging and the row factor afterwards, as in
-// the decode kernels.  The split matters because a wave's loads retire in order: a wave that both
+// of the block (rows that need an RMSNorm are normalised by kg_rmsnorm_kernel beforehand, once per pass
+// instead of once per block).  The split matters because a wave's loads retire in order: a wave that both
 // streams weights several batches ahead and waits for the next X batch drains its own weight
 // queue at every step (measured: half of a block's time went into that wait).  The accumulators
 // go through the decode kernels' own epilogue code, so rounding is identical.
@@ -28,7 +28,7 @@ static_assert(GEMM_KB == 4, "the LDS swizzle assumes 256-byte rows");
 
 // GEMM_NW = waves (= weight row groups) per block: 4 shares one staged X batch among more
 // row groups; 2 keeps 128 blocks for the 4096-row projections.
-template <int DT, int PRO, int EPI, int GEMM_NW>
+template <int DT, int EPI, int GEMM_NW>
 __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const KgLinArgs a) {
     constexpr int GEMM_STAGE = KG_GEMM_ROWS * (GEMM_KB * 4) / (GEMM_LW * 64);    // 16-byte pieces of a batch each loader thread stages
     constexpr int PPR = GEMM_KB * 4;                                   // 16-byte pieces per X row of a batch
@@ -48,11 +48,9 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs0 = smem;
     char* xs1 = smem + KG_GEMM_ROWS * GEMM_XROW;
-    float* ssum = (float*)(smem + 2 * KG_GEMM_ROWS * GEMM_XROW);       // [KG_GEMM_ROWS] sum of squares per row
 
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (int)((size_t)G * KT * 1024), 0x00020000);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(((size_t)(M - 1) * a.x_stride + a.K) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(PRO == PRO_RMSNORM ? a.norm_w : a.x), 0, a.K * 2, 0x00020000);
 
     // Blocks walk K in rotated order (block i starts at batch 5 i mod NB): otherwise every block
     // asks for the same X columns at the same moment and those few L2 channels serialise the grid.
@@ -72,7 +70,7 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
     };
     // staging: piece q = tid + nthreads * j covers row q / PPR, 16-byte column q % PPR of the batch
     const int scol = (ltid & (PPR - 1)), srow0 = (ltid >= 0 ? ltid : 0) / PPR;
-    auto stage_load = [&](kg_u4 (&sx)[GEMM_STAGE], kg_u4& gw, int step) {
+    auto stage_load = [&](kg_u4 (&sx)[GEMM_STAGE], int step) {
         const int b = kbatch(step);
         const bool kok = (GEMM_KB * b + (scol >> 2)) < KT;
 #pragma unroll
@@ -81,30 +79,10 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
             const bool ok = kok && row < M;
             sx[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(((size_t)row * a.x_stride + 32 * GEMM_KB * b + 8 * scol) * 2) : 0xFFFFFFFFu, 0, 0);
         }
-        if (PRO == PRO_RMSNORM) gw = __builtin_amdgcn_raw_buffer_load_b128(nrsrc, kok ? (unsigned)((32 * GEMM_KB * b + 8 * scol) * 2) : 0xFFFFFFFFu, 0, 0);
     };
-    float ss[GEMM_STAGE];
+    auto stage_store = [&](const kg_u4 (&sx)[GEMM_STAGE], char* xs) {
 #pragma unroll
-    for (int j = 0; j < GEMM_STAGE; ++j) ss[j] = 0.f;
-    auto stage_store = [&](const kg_u4 (&sx)[GEMM_STAGE], const kg_u4& gw, char* xs) {
-        const kg_us8 gg = __builtin_bit_cast(kg_us8, gw);
-#pragma unroll
-        for (int j = 0; j < GEMM_STAGE; ++j) {
-            const int row = srow0 + RPJ * j;
-            kg_u4 v = sx[j];
-            if (PRO == PRO_RMSNORM) {
-                kg_us8 h = __builtin_bit_cast(kg_us8, v);
-                kg_us8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float f = T::to_f(h[e]);
-                    ss[j] += f * f;
-                    o[e] = T::from_f(T::to_f(gg[e]) * f);
-                }
-                v = __builtin_bit_cast(kg_u4, o);
-            }
-            *(kg_u4*)(xs + GEMM_XOFF(row, scol)) = v;
-        }
+        for (int j = 0; j < GEMM_STAGE; ++j) *(kg_u4*)(xs + GEMM_XOFF(srow0 + RPJ * j, scol)) = sx[j];
     };
 
     kg_f4 acc[KG_GEMM_ROWS / 16];
@@ -139,13 +117,11 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
 #define GEMM_TL(var, t0_) do { } while (0)
 #endif
     if (loader) {
-        kg_u4 sx[XS][GEMM_STAGE], gw[XS];
+        kg_u4 sx[XS][GEMM_STAGE];
 #pragma unroll
-        for (int i = 0; i < XS; ++i) gw[i] = kg_u4{0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int i = 0; i < XS; ++i) stage_load(sx[i], gw[i], i);
-        stage_store(sx[0], gw[0], xs0);
-        stage_load(sx[0], gw[0], XS);
+        for (int i = 0; i < XS; ++i) stage_load(sx[i], i);
+        stage_store(sx[0], xs0);
+        stage_load(sx[0], XS);
         __syncthreads();
         for (int b = 0; b < NBL; b += U) {
 #pragma unroll
@@ -154,9 +130,9 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
 #ifdef KG_LIN_TLOG
                 unsigned long long tl0 = wall_clock64();
 #endif
-                stage_store(sx[(i + 1) % XS], gw[(i + 1) % XS], (bb & 1) ? xs0 : xs1);      // X(bb + 1)
+                stage_store(sx[(i + 1) % XS], (bb & 1) ? xs0 : xs1);      // X(bb + 1)
                 GEMM_TL(tl_store, tl0);
-                stage_load(sx[(i + 1) % XS], gw[(i + 1) % XS], bb + 1 + XS);
+                stage_load(sx[(i + 1) % XS], bb + 1 + XS);
                 GEMM_TL(tl_issue, tl0);
                 __syncthreads();
                 GEMM_TL(tl_barrier, tl0);
@@ -195,16 +171,6 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
         tl[4] = tl_store;
     }
 #endif
-    // ---- row factors of the deferred RMSNorm ----
-    if (PRO == PRO_RMSNORM && loader) {
-#pragma unroll
-        for (int j = 0; j < GEMM_STAGE; ++j) {
-            float t = ss[j];
-#pragma unroll
-            for (int o = 1; o < PPR; o <<= 1) t += __shfl_xor(t, o, 64);
-            if ((lane & (PPR - 1)) == 0) ssum[srow0 + RPJ * j] = t;
-        }
-    }
     // ---- epilogue inputs through LDS (the X buffers are free now), laid out as the decode epilogues expect ----
     char* side = (EPI == EPI_RESID) ? xs0 + (size_t)(loader ? 0 : wave) * KG_GEMM_ROWS * 32 : xs0;
     if (EPI == EPI_RESID && KS > 1) {
@@ -245,10 +211,9 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
     for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) {
         const int m = 16 * cb + r;
         if (m < M) {
-            const float rstd = (PRO == PRO_RMSNORM) ? rsqrtf(ssum[m] / (float)a.K + a.eps) : 1.f;
             // lane holds D[weight row 4g + i][column m], i = 0..3: two adjacent-row pairs
-            epilogue_pair<DT, EPI, false>(a, rg * 16 + 4 * g, m, pos0 + m, acc[cb][0] * rstd, acc[cb][1] * rstd, run, side, 0, M);
-            epilogue_pair<DT, EPI, false>(a, rg * 16 + 4 * g + 2, m, pos0 + m, acc[cb][2] * rstd, acc[cb][3] * rstd, run, side, 0, M);
+            epilogue_pair<DT, EPI, false>(a, rg * 16 + 4 * g, m, pos0 + m, acc[cb][0], acc[cb][1], run, side, 0, M);
+            epilogue_pair<DT, EPI, false>(a, rg * 16 + 4 * g + 2, m, pos0 + m, acc[cb][2], acc[cb][3], run, side, 0, M);
         }
     }
     KG_TSTAMP(a, 7);
@@ -278,23 +243,23 @@ __global__ void kg_gemm_reduce_kernel(const KgLinArgs a) {
 }
 
 static int g_gemm_ncu = 256;
-static size_t gemm_smem() { return (size_t)2 * KG_GEMM_ROWS * GEMM_XROW + KG_GEMM_ROWS * sizeof(float); }
+static size_t gemm_smem() { return (size_t)2 * KG_GEMM_ROWS * GEMM_XROW; }
 
-template <int DT, int PRO, int NW>
+template <int DT, int NW>
 static int launch_epi(const KgLinArgs& a, int epi, hipStream_t st) {
     const int G = (a.N + 15) / 16;
     const dim3 grid((G + NW - 1) / NW, a.ksplit > 1 ? a.ksplit : 1), block((NW + GEMM_LW) * 64);
     const size_t smem = gemm_smem();
     switch (epi) {
-    case EPI_STORE: hipLaunchKernelGGL((kg_gemm_kernel<DT, PRO, EPI_STORE, NW>), grid, block, smem, st, a); break;
-    case EPI_RESID: hipLaunchKernelGGL((kg_gemm_kernel<DT, PRO, EPI_RESID, NW>), grid, block, smem, st, a); break;
-    case EPI_ROPE_KV: hipLaunchKernelGGL((kg_gemm_kernel<DT, PRO, EPI_ROPE_KV, NW>), grid, block, smem, st, a); break;
-    case EPI_SILU_MUL: hipLaunchKernelGGL((kg_gemm_kernel<DT, PRO, EPI_SILU_MUL, NW>), grid, block, smem, st, a); break;
+    case EPI_STORE: hipLaunchKernelGGL((kg_gemm_kernel<DT, EPI_STORE, NW>), grid, block, smem, st, a); break;
+    case EPI_RESID: hipLaunchKernelGGL((kg_gemm_kernel<DT, EPI_RESID, NW>), grid, block, smem, st, a); break;
+    case EPI_ROPE_KV: hipLaunchKernelGGL((kg_gemm_kernel<DT, EPI_ROPE_KV, NW>), grid, block, smem, st, a); break;
+    case EPI_SILU_MUL: hipLaunchKernelGGL((kg_gemm_kernel<DT, EPI_SILU_MUL, NW>), grid, block, smem, st, a); break;
     default: return -1;
     }
     return 0;
 }
-template <int DT, int PRO>
+template <int DT>
 static int launch_nw(const KgLinArgs& a, int epi, hipStream_t st) {
     // Row groups per block (= compute waves): a block's step costs about as much LDS and MFMA time as it
     // has compute waves, and the launch takes ceil(blocks / CUs) rounds of blocks, so pick the count that
@@ -309,9 +274,9 @@ static int launch_nw(const KgLinArgs& a, int epi, hipStream_t st) {
     const char* force = getenv("KG_GEMM_NW");
     if (force) best = atoi(force);
     switch (best) {
-    case 4: return launch_epi<DT, PRO, 4>(a, epi, st);
-    case 3: return launch_epi<DT, PRO, 3>(a, epi, st);
-    default: return launch_epi<DT, PRO, 2>(a, epi, st);
+    case 4: return launch_epi<DT, 4>(a, epi, st);
+    case 3: return launch_epi<DT, 3>(a, epi, st);
+    default: return launch_epi<DT, 2>(a, epi, st);
     }
 }
 
@@ -329,8 +294,8 @@ int kg_launch_gemm(const KgLinArgs& a_in, int dtype, int pro, int epi, hipStream
     }
     if (epi == EPI_ROPE_KV && (size_t)KG_GEMM_ROWS * a.head_dim * 4 > (size_t)2 * KG_GEMM_ROWS * GEMM_XROW) return -1;     // cos/sin rows reuse both X buffers
     int rc;
-    if (dtype == KG_F16) rc = (pro == PRO_NONE) ? launch_nw<KG_F16, PRO_NONE>(a, epi, st) : launch_nw<KG_F16, PRO_RMSNORM>(a, epi, st);
-    else rc = (pro == PRO_NONE) ? launch_nw<KG_BF16, PRO_NONE>(a, epi, st) : launch_nw<KG_BF16, PRO_RMSNORM>(a, epi, st);
+    if (pro != PRO_NONE) return -1;          // rows are normalised by kg_launch_rmsnorm before the pass
+    rc = (dtype == KG_F16) ? launch_nw<KG_F16>(a, epi, st) : launch_nw<KG_BF16>(a, epi, st);
     if (rc) return rc;
     if (a.ksplit > 1) {
         const dim3 grid((a.N / 4 + 255) / 256, KG_GEMM_ROWS);
@@ -340,21 +305,18 @@ int kg_launch_gemm(const KgLinArgs& a_in, int dtype, int pro, int epi, hipStream
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-template <int DT, int PRO, int NW> static void set_attr_all() {
+template <int DT, int NW> static void set_attr_all() {
     const int lim = (int)gemm_smem();
-    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, PRO, EPI_STORE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, PRO, EPI_RESID, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, PRO, EPI_ROPE_KV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, PRO, EPI_SILU_MUL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, EPI_STORE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, EPI_RESID, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, EPI_ROPE_KV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, EPI_SILU_MUL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
 }
 void kg_gemm_init() {
     int dev = 0, ncu = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) g_gemm_ncu = ncu;
-    set_attr_all<KG_F16, PRO_NONE, 2>(); set_attr_all<KG_F16, PRO_RMSNORM, 2>();
-    set_attr_all<KG_BF16, PRO_NONE, 2>(); set_attr_all<KG_BF16, PRO_RMSNORM, 2>();
-    set_attr_all<KG_F16, PRO_NONE, 3>(); set_attr_all<KG_F16, PRO_RMSNORM, 3>();
-    set_attr_all<KG_BF16, PRO_NONE, 3>(); set_attr_all<KG_BF16, PRO_RMSNORM, 3>();
-    set_attr_all<KG_F16, PRO_NONE, 4>(); set_attr_all<KG_F16, PRO_RMSNORM, 4>();
-    set_attr_all<KG_BF16, PRO_NONE, 4>(); set_attr_all<KG_BF16, PRO_RMSNORM, 4>();
+    set_attr_all<KG_F16, 2>(); set_attr_all<KG_BF16, 2>();
+    set_attr_all<KG_F16, 3>(); set_attr_all<KG_BF16, 3>();
+    set_attr_all<KG_F16, 4>(); set_attr_all<KG_BF16, 4>();
     (void)hipGetLastError();
 }

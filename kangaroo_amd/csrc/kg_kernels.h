@@ -79,6 +79,8 @@ int kg_launch_rmsnorm(const KgDyn* dyn, const void* x, int x_stride, const void*
 int kg_launch_head_finalize(const KgDyn* dyn, const float* head_part, int head_part_stride, int nblocks, int max_rows,
                             int* tok_out, float* pmax_out, hipStream_t st);
 
+int kg_launch_logit_records(const void* logits, int vocab, int rows, int nblocks, float* head_part, int stride, int dtype, hipStream_t st);
+
 struct KgLoopBufs {
     int* state;                 // KS_* layout
     int* tokens;                // [max_length]

@@ -160,39 +160,84 @@ __device__ __forceinline__ void epilogue_pair(const KgLinArgs& a, int n0, int m,
 // keeps them in registers; prologue_finish runs after the weight loads are in flight, so
 // the norm and the LDS fill overlap the first HBM round trip (the memory counter retires
 // in order: x requested first is waited for with the weight loads still outstanding).
-// RMSNorm is applied in two halves: the prologue stores gamma[k] * x[m][k] (rounded to the
-// model dtype) and every thread keeps the sum of squares of the chunks it touched; the row
-// factor rsqrt(mean(x^2) + eps) multiplies the finished dot products in the epilogue, after
-// the partial sums of squares have met in LDS at the first row group's barrier.  The norm
-// therefore costs no barrier and no reduction before the weight stream starts.
+// RMSNorm follows the reference's order of operations (kangaroo/adapter.py:254-259): the row factor
+// rsqrt(mean(x^2) + eps) is formed first (per-thread partial sums, one wave butterfly, one LDS slot per
+// wave, one block barrier), x * factor is rounded to the model dtype, and the product with gamma is rounded
+// again.  The extra barrier sits in the shadow of the first weight round trip.
 // NS register slots of 16 bytes: slot i holds chunk set i % SETS of row i / SETS (SETS = chunks of a row per thread)
 template <int NS> struct ProRegs { kg_u4 v[NS]; kg_u4 gw[2]; };
 
-template <int DT, int PRO, int RM, bool COH_LD>
-__device__ __forceinline__ void prologue_slow(const KgLinArgs& a, char* xs, int xs_stride, float (&ss)[RM], int M, int row_off,
-                                              int tid, int nthreads) {
+// Row factors of the RMSNorm: every thread adds the squares of the chunks it owns, a wave butterfly and
+// one LDS slot per (row, wave) follow, and after a block barrier every thread sums the wave slots in wave
+// order.  The order of the additions depends on the thread count only, never on the rows riding along.
+template <int RM>
+__device__ __forceinline__ void rms_row_factors(float (&ss)[RM], float* red2, int M, int K, float eps, int lane, int wave, int nwaves) {
+#pragma unroll
+    for (int m = 0; m < RM; ++m) {
+        if (m < M) {
+            const float t = kg_wave_sum(ss[m]);
+            if (lane == 0) red2[m * nwaves + wave] = t;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < RM; ++m) {
+        if (m < M) {
+            float tot = 0.f;
+            for (int w = 0; w < nwaves; ++w) tot += red2[m * nwaves + w];
+            ss[m] = rsqrtf(tot / (float)K + eps);
+        }
+    }
+}
+
+// y = gamma * round16(x * rstd), rounded again: the order of kangaroo/adapter.py:254-259
+template <int DT>
+__device__ __forceinline__ kg_u4 rms_apply(kg_u4 xv, kg_u4 gv, float rstd) {
     typedef KgT<DT> T;
+    const kg_us8 h = __builtin_bit_cast(kg_us8, xv), g = __builtin_bit_cast(kg_us8, gv);
+    kg_us8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = T::from_f(T::to_f(g[j]) * kg_round<DT>(T::to_f(h[j]) * rstd));
+    return __builtin_bit_cast(kg_u4, o);
+}
+template <int DT>
+__device__ __forceinline__ float sum_sq8(kg_u4 xv) {
+    typedef KgT<DT> T;
+    const kg_us8 h = __builtin_bit_cast(kg_us8, xv);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float f = T::to_f(h[j]); s += f * f; }
+    return s;
+}
+
+// K beyond what the register slots hold: two sweeps over the rows (sum of squares, then normalise and store)
+template <int DT, int PRO, int RM, bool COH_LD>
+__device__ __forceinline__ void prologue_slow(const KgLinArgs& a, char* xs, int xs_stride, float* red2, int M, int row_off,
+                                              int tid, int nthreads, int lane, int wave, int nwaves) {
     const int nchunk = a.K >> 3;
     const kg_u4* wn = (const kg_u4*)a.norm_w;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0,
         (int)(((size_t)(M - 1 + row_off) * a.x_stride + a.K) * 2), 0x00020000);
+    float ss[RM];
+#pragma unroll
+    for (int m = 0; m < RM; ++m) ss[m] = 0.f;
+    if (PRO == PRO_RMSNORM) {
+#pragma unroll
+        for (int m = 0; m < RM; ++m) {
+            if (m < M) {
+                for (int c = tid; c < nchunk; c += nthreads)
+                    ss[m] += sum_sq8<DT>(__builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(((size_t)(m + row_off) * a.x_stride) * 2 + (size_t)c * 16), 0, COH_LD ? KG_AUX_COH : 0));
+            }
+        }
+        rms_row_factors<RM>(ss, red2, M, a.K, a.eps, lane, wave, nwaves);
+    }
 #pragma unroll
     for (int m = 0; m < RM; ++m) {
         if (m < M) {
             kg_u4* dst = (kg_u4*)(xs + (size_t)m * xs_stride);
             for (int c = tid; c < nchunk; c += nthreads) {
                 const kg_u4 xv = __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(((size_t)(m + row_off) * a.x_stride) * 2 + (size_t)c * 16), 0, COH_LD ? KG_AUX_COH : 0);
-                if (PRO == PRO_NONE) { dst[c] = xv; continue; }
-                kg_us8 h = __builtin_bit_cast(kg_us8, xv);
-                kg_us8 g = __builtin_bit_cast(kg_us8, wn[c]);
-                kg_us8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float f = T::to_f(h[j]);
-                    ss[m] += f * f;
-                    o[j] = T::from_f(T::to_f(g[j]) * f);
-                }
-                dst[c] = __builtin_bit_cast(kg_u4, o);
+                dst[c] = (PRO == PRO_NONE) ? xv : rms_apply<DT>(xv, wn[c], ss[m]);
             }
         }
     }
@@ -221,30 +266,29 @@ __device__ __forceinline__ void prologue_load(const KgLinArgs& a, ProRegs<NS>& p
 }
 
 template <int DT, int PRO, int NS, int RM, int SETS>
-__device__ __forceinline__ void prologue_finish(const KgLinArgs& a, const ProRegs<NS>& pr, char* xs, int xs_stride, float (&ss)[RM], int M,
-                                                int tid, int nthreads) {
-    typedef KgT<DT> T;
+__device__ __forceinline__ void prologue_finish(const KgLinArgs& a, const ProRegs<NS>& pr, char* xs, int xs_stride, float* red2, int M,
+                                                int tid, int nthreads, int lane, int wave, int nwaves) {
     const int nchunk = a.K >> 3;
+    float ss[RM];
+#pragma unroll
+    for (int m = 0; m < RM; ++m) ss[m] = 0.f;
+    if (PRO == PRO_RMSNORM) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int m = i / SETS, c = tid + (i % SETS) * nthreads;
+            if (i / SETS < RM) {
+                if (m < M && c < nchunk) ss[i / SETS < RM ? i / SETS : 0] += sum_sq8<DT>(pr.v[i]);
+            }
+        }
+        rms_row_factors<RM>(ss, red2, M, a.K, a.eps, lane, wave, nwaves);
+    }
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int m = i / SETS, c = tid + (i % SETS) * nthreads;
         if (i / SETS < RM) {
-            if (m < M && c < nchunk) {
-                if (PRO == PRO_NONE) {
-                    *(kg_u4*)(xs + (size_t)m * xs_stride + (size_t)c * 16) = pr.v[i];
-                } else {
-                    kg_us8 g = __builtin_bit_cast(kg_us8, pr.gw[i % SETS]);
-                    kg_us8 h = __builtin_bit_cast(kg_us8, pr.v[i]);
-                    kg_us8 o;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float f = T::to_f(h[j]);
-                        ss[i / SETS < RM ? i / SETS : 0] += f * f;
-                        o[j] = T::from_f(T::to_f(g[j]) * f);
-                    }
-                    *(kg_u4*)(xs + (size_t)m * xs_stride + (size_t)c * 16) = __builtin_bit_cast(kg_u4, o);
-                }
-            }
+            if (m < M && c < nchunk)
+                *(kg_u4*)(xs + (size_t)m * xs_stride + (size_t)c * 16) =
+                    (PRO == PRO_NONE) ? pr.v[i] : rms_apply<DT>(pr.v[i], pr.gw[i % SETS], ss[i / SETS < RM ? i / SETS : 0]);
         }
     }
 }
@@ -324,7 +368,8 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
     const int bid = bid_;
     const int nrg_blk = (G - bid + (int)gridDim.x - 1) / (int)gridDim.x;
     if (idle) {
-        // same barrier sequence as the working waves: one after the prologue, one per row group
+        // same barrier sequence as the working waves: the norm's (if any), one after the prologue, one per row group
+        if (PRO == PRO_RMSNORM && MODE != MODE_MFMA_GX) __syncthreads();
         __syncthreads();
         for (int i = 0; i < nrg_blk; ++i) __syncthreads();
         gb->arrive();
@@ -346,13 +391,9 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
     const int pro_sets = ((a.K >> 3) <= nthreads) ? 1 : 2;
     const bool pro_fast = (a.K >> 3) <= pro_sets * nthreads && M * pro_sets <= NS;
     ProRegs<NS> pr;
-    float ss[RM];                                                // this thread's share of sum(x^2) per row
-#pragma unroll
-    for (int m = 0; m < RM; ++m) ss[m] = 0.f;
-    if (MODE != MODE_MFMA_GX) {
-        if (pro_fast && pro_sets == 1) prologue_load<PRO, NS, 1, COH_LD>(a, pr, M, row_off, tid, nthreads);
-        else if (pro_fast) prologue_load<PRO, NS, 2, COH_LD>(a, pr, M, row_off, tid, nthreads);
-        else prologue_slow<DT, PRO, RM, COH_LD>(a, xs, xs_stride, ss, M, row_off, tid, nthreads);
+    if (MODE != MODE_MFMA_GX && pro_fast) {
+        if (pro_sets == 1) prologue_load<PRO, NS, 1, COH_LD>(a, pr, M, row_off, tid, nthreads);
+        else prologue_load<PRO, NS, 2, COH_LD>(a, pr, M, row_off, tid, nthreads);
     }
     unsigned side_raw[2] = {0u, 0u};
     const int side_n = (EPI == EPI_RESID) ? nrg_blk * M * 16 : (EPI == EPI_ROPE_KV) ? M * a.head_dim : 0;
@@ -449,15 +490,15 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
             }
         }
     }
-    if (MODE != MODE_MFMA_GX && pro_fast) {
-        if (pro_sets == 1) prologue_finish<DT, PRO, NS, RM, 1>(a, pr, xs, xs_stride, ss, M, tid, nthreads);
-        else prologue_finish<DT, PRO, NS, RM, 2>(a, pr, xs, xs_stride, ss, M, tid, nthreads);
+    if (MODE != MODE_MFMA_GX) {
+        if (!pro_fast) prologue_slow<DT, PRO, RM, COH_LD>(a, xs, xs_stride, red2, M, row_off, tid, nthreads, lane, wave, nwaves);
+        else if (pro_sets == 1) prologue_finish<DT, PRO, NS, RM, 1>(a, pr, xs, xs_stride, red2, M, tid, nthreads, lane, wave, nwaves);
+        else prologue_finish<DT, PRO, NS, RM, 2>(a, pr, xs, xs_stride, red2, M, tid, nthreads, lane, wave, nwaves);
     }
     __syncthreads();
     KG_TSTAMP(a, 2);
 
     HeadRun run; run.mx = -INFINITY; run.sum = 0.f; run.idx = 0;
-    float rstd = 1.f;
     int it = 0, ct = t0;
     kg_f4 acc = {0.f, 0.f, 0.f, 0.f};
     float acc0 = 0.f, acc1 = 0.f;
@@ -509,32 +550,17 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
                 // lane holds D[row 4g+i][col r]; store as [col][row] so a pair reads 2 floats
                 *(kg_f4*)(slot + wave * 256 + r * 16 + g * 4) = acc;
             }
-            if (PRO == PRO_RMSNORM && it == 0) {
-#pragma unroll
-                for (int m = 0; m < RM; ++m) {
-                    if (m < M) {
-                        const float t = kg_wave_sum(ss[m]);
-                        if (lane == 0) red2[m * nwaves + wave] = t;
-                    }
-                }
-            }
             __syncthreads();
             if (it == 0) KG_TSTAMP(a, 3);
             const int n_epi = (MODE == MODE_VEC) ? 8 : 128;
             if (tid < n_epi) {
                 const int m = tid >> 3, p = tid & 7;
                 if (m < M) {
-                    if (PRO == PRO_RMSNORM && it == 0) {
-                        float tot = 0.f;
-                        for (int w = 0; w < nwaves; ++w) tot += red2[m * nwaves + w];
-                        rstd = rsqrtf(tot / (float)a.K + a.eps);
-                    }
                     float v0 = 0.f, v1 = 0.f;
                     for (int w = 0; w < nwaves; ++w) {
                         const float* sp = slot + w * PART + m * 16 + 2 * p;
                         v0 += sp[0]; v1 += sp[1];
                     }
-                    if (PRO == PRO_RMSNORM) { v0 *= rstd; v1 *= rstd; }
                     epilogue_pair<DT, EPI, COH>(a, rg * 16 + 2 * p, m, my_pos, v0, v1, run, side, it, M);
                 }
             }

@@ -88,6 +88,7 @@ template <int DT, int MODE, int PRO> static void set_attr_epi() {
 void kg_linear_init() {
     set_attr_epi<KG_F16, MODE_MFMA, PRO_NONE>(); set_attr_epi<KG_F16, MODE_MFMA, PRO_RMSNORM>();
     set_attr_epi<KG_BF16, MODE_MFMA, PRO_NONE>(); set_attr_epi<KG_BF16, MODE_MFMA, PRO_RMSNORM>();
+    set_attr_epi<KG_F16, MODE_MFMA_GX, PRO_NONE>(); set_attr_epi<KG_BF16, MODE_MFMA_GX, PRO_NONE>();
     set_attr_epi<KG_F16, MODE_VEC, PRO_NONE>(); set_attr_epi<KG_F16, MODE_VEC, PRO_RMSNORM>();
     set_attr_epi<KG_BF16, MODE_VEC, PRO_NONE>(); set_attr_epi<KG_BF16, MODE_VEC, PRO_RMSNORM>();
 }

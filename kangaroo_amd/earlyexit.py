@@ -18,6 +18,18 @@ import torch
 from .engine import KangarooEngine
 
 
+def _check_positions(position_ids, past: int, n: int):
+    """Cache slot == position id on this path: the rows of a pass sit at positions past .. past+n-1, which is
+    what the reference's loop passes (evaluation/inference_kangaroo.py:29,57,60,86) and what
+    kangaroo/earlyexit.py:34-39 defaults to.  Anything else is refused (host or device tensor alike; a device
+    tensor costs one read-back here, in the pass-by-pass interface only)."""
+    if position_ids is None:
+        return
+    got = position_ids.reshape(-1).tolist()
+    if got != list(range(past, past + n)):
+        raise ValueError(f"position ids must continue the cache (slot == position): expected {past}..{past + n - 1}, got {got[:4]}{'...' if len(got) > 4 else ''}")
+
+
 class _HiddenStates:
     """hidden_states of the prefill output: index EARLY_STOP_LAYER (input of the exit
     layer) and -1 / N (after the final norm) are materialised; the loop reads only those
@@ -65,8 +77,7 @@ class EarlyExitLlamaForCausalLM:
         return self.engine.kv_views(layer, length)
 
     def _chunk_rows(self) -> int:
-        d = self.engine.shape.hidden_size
-        return 16 if 16 * (2 * d + 32) <= 160 * 1024 - 16 * 1024 else 8
+        return self.engine.get_tuning("prefill_rows")
 
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
@@ -78,6 +89,7 @@ class EarlyExitLlamaForCausalLM:
         T = ids.numel()
         if T > e.max_length:
             raise ValueError("prompt longer than the cache")
+        _check_positions(position_ids, 0, T)
         e.set_tokens(ids, 0)
         L, N, d = self.early_exit_layer, e.shape.num_hidden_layers, e.shape.hidden_size
         C = self._chunk_rows()
@@ -115,9 +127,7 @@ class EarlyExitLlamaForCausalLM:
         small = in_tokens_small is not None
         focus = 0 if small else self.early_exit_layer
         past = self.past_key_values[focus][0].shape[2]
-        if position_ids is not None and not position_ids.is_cuda:
-            if int(position_ids.reshape(-1)[0]) != past:
-                raise ValueError("position ids must continue the cache (slot == position)")
+        _check_positions(position_ids, past, seq_length)
         if small:
             e.set_tokens(in_tokens_small, past)
             h = e.forward_layers(0, self.early_exit_layer, None, past, seq_length)

@@ -214,6 +214,8 @@ class KangarooEngine:
 
     def set_tokens(self, ids: torch.Tensor, pos0: int):
         ids = ids.reshape(-1)
+        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.shape.vocab_size):
+            raise ValueError("token id out of range")          # the embedding gather has no bounds check on the device
         self.tokens[pos0:pos0 + ids.numel()] = ids.to(device=self.device, dtype=torch.int32)
 
     def bench_op(self, op: str, rows: int, iters: int = 64):

@@ -291,6 +291,40 @@ class Trace:
     prefill_last_logits: Optional[torch.Tensor] = None
 
 
+def accept_block(logits, global_tokens, start_index, end_index, eos_token_id, accept_top_k=1, accept_top_p=None, temperature=1.0):
+    """The verification block of one round, evaluation/inference_kangaroo.py:92-102 (greedy) with the
+    membership tests of evaluation/inference_kangaroo_MTBench.py:356-389 swapped in for :97 when asked.
+    logits: [1, q, V] fp32 verify logits of rows start_index .. end_index-1; global_tokens is updated in
+    place (:98).  Returns (new start_index, stop)."""
+    output_tokens = torch.argmax(logits, dim=-1)                                                  # :92
+    stop = False
+    output_length = end_index - start_index                                                       # :95
+    if accept_top_p is not None:
+        probs = torch.softmax(logits / temperature, dim=-1)                                       # MTBench :358-359
+        # MTBench :360 calls torch.sort(probs, descending=True), which leaves the order of EQUAL probabilities to
+        # the backend; stable=True pins it (token-id order) and changes nothing where no two probabilities tie
+        sorted_probs, sorted_indices = torch.sort(probs, descending=True, stable=True)
+        keep = torch.roll(sorted_probs.cumsum(dim=-1) <= accept_top_p, 1, dims=-1)                # MTBench :361-363
+        keep[..., 0] = True                                                                       # MTBench :364
+        pooled_nucleus = sorted_indices[keep]                                                     # MTBench :365
+    elif accept_top_k > 1:
+        output_topk_tokens = torch.topk(logits, k=accept_top_k, dim=-1).indices                   # MTBench :379
+    for i in range(output_length):                                                                # :96
+        if accept_top_p is not None:
+            rejected = global_tokens[0, start_index + 1 + i] not in pooled_nucleus                # MTBench :369
+        elif accept_top_k > 1:
+            rejected = global_tokens[0, start_index + 1 + i] not in output_topk_tokens[0, i, :]   # MTBench :384
+        else:
+            rejected = output_tokens[0, i] != global_tokens[0, start_index + 1 + i]               # :97
+        if i == output_length - 1 or output_tokens[0, i] == eos_token_id or rejected:
+            global_tokens[0, start_index + 1 + i] = output_tokens[0, i]                           # :98
+            start_index = start_index + 1 + i                                                     # :99
+            if output_tokens[0, i] == eos_token_id:                                               # :100
+                stop = True
+            break
+    return start_index, stop
+
+
 def kangaroo_forward(input_ids: torch.Tensor, model, eos_token_id: int, max_new_tokens: int,
                      max_length: int = 2048, EARLY_STOP_LAYER: int = 2, SPECULATIVE_DECODING_STEPS: int = 6,
                      threshold: float = 0.6, trace: Optional[Trace] = None, keep_logits: bool = False,
@@ -310,9 +344,10 @@ def kangaroo_forward(input_ids: torch.Tensor, model, eos_token_id: int, max_new_
 
     Returns ([output_ids], new_token, idx, accept_length_list)."""
     context_tokens = input_ids
+    device = context_tokens.device                                                                # :17
     batch_size, context_length = context_tokens.shape
-    global_tokens = torch.ones((batch_size, max_length), dtype=torch.long) * eos_token_id      # :20
-    global_position_ids = torch.arange(max_length).view(1, -1)                                   # :21
+    global_tokens = torch.ones((batch_size, max_length), dtype=torch.long, device=device) * eos_token_id   # :20
+    global_position_ids = torch.arange(max_length, device=device).view(1, -1)                    # :21
     accept_length_list = [1]                                                                      # :22
     start_index = context_length                                                                  # :24
     global_tokens[:, :start_index] = context_tokens                                               # :25
@@ -379,28 +414,9 @@ def kangaroo_forward(input_ids: torch.Tensor, model, eos_token_id: int, max_new_
             if keep_logits:
                 trace.verify_logits.append(logits[0].clone())
 
-        output_length = end_index - start_index                                                   # :95
-        if accept_top_p is not None:
-            probs = torch.softmax(logits / temperature, dim=-1)                                   # MTBench :358-359
-            sorted_probs, sorted_indices = torch.sort(probs, descending=True)                     # MTBench :360
-            keep = torch.roll(sorted_probs.cumsum(dim=-1) <= accept_top_p, 1, dims=-1)            # MTBench :361-363
-            keep[..., 0] = True                                                                   # MTBench :364
-            pooled_nucleus = sorted_indices[keep]                                                 # MTBench :365
-        elif accept_top_k > 1:
-            output_topk_tokens = torch.topk(logits, k=accept_top_k, dim=-1).indices               # MTBench :379
-        for i in range(output_length):                                                            # :96
-            if accept_top_p is not None:
-                rejected = global_tokens[0, start_index + 1 + i] not in pooled_nucleus            # MTBench :369
-            elif accept_top_k > 1:
-                rejected = global_tokens[0, start_index + 1 + i] not in output_topk_tokens[0, i, :]   # MTBench :384
-            else:
-                rejected = output_tokens[0, i] != global_tokens[0, start_index + 1 + i]           # :97
-            if i == output_length - 1 or output_tokens[0, i] == eos_token_id or rejected:
-                global_tokens[0, start_index + 1 + i] = output_tokens[0, i]                       # :98
-                start_index = start_index + 1 + i                                                 # :99
-                if output_tokens[0, i] == eos_token_id:                                           # :100
-                    stop = True
-                break
+        start_index, stop_now = accept_block(logits, global_tokens, start_index, end_index, eos_token_id,   # :95-102
+                                             accept_top_k, accept_top_p, temperature)
+        stop = stop or stop_now
         accept_length_list.append(start_index - start_index_copy)                                 # :104
 
         if model.base_model.past_key_values[0][0].shape[2] > start_index:                         # :108

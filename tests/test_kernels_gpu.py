@@ -48,7 +48,7 @@ def test_linear_store(dtype, code, N, K, rows):
     wp = pack_weight(w.to(DEV))
     xd = x.to(DEV)
     out = torch.full((rows, N), float("nan"), dtype=dtype, device=DEV)
-    scratch = torch.zeros(256, dtype=torch.uint8, device=DEV)
+    scratch = torch.zeros(lib.kg_linear_scratch_bytes(rows, K), dtype=torch.uint8, device=DEV)
     for nblocks, nwaves in [(0, 0), (3, 4), (1000, 2)]:
         out.fill_(float("nan"))
         _lib.check(lib.kg_linear(code, vp(wp), N, K, vp(xd), rows, 0, None, 0.0, 0, None, vp(out), N, vp(scratch), nblocks, nwaves, stream()), "kg_linear")
@@ -68,7 +68,7 @@ def test_linear_rmsnorm_resid_silu(dtype, code, rows):
     wg = (torch.randn(F, d, generator=g) / math.sqrt(d)).to(dtype)
     wu = (torch.randn(F, d, generator=g) / math.sqrt(d)).to(dtype)
     wd = (torch.randn(d, F, generator=g) / math.sqrt(F)).to(dtype)
-    scratch = torch.zeros(256, dtype=torch.uint8, device=DEV)
+    scratch = torch.zeros(lib.kg_linear_scratch_bytes(rows, F), dtype=torch.uint8, device=DEV)
     # gate/up with RMSNorm prologue and SiLU*mul epilogue
     xn = ko.rmsnorm(x.float(), nw.float(), 1e-6, round_to=dtype)
     act_ref = torch.nn.functional.silu(xn @ wg.float().T) * (xn @ wu.float().T)
@@ -119,7 +119,7 @@ def test_qkv_rope_attention(dtype, code, H, Hkv, hd, rows, pos0):
     vrows(0, pos0).copy_(past_v.to(DEV))
     cos, sin = rope_tables(hd, 2048, device=DEV)
     q = torch.empty((rows, H * hd), dtype=dtype, device=DEV)
-    scratch = torch.zeros(256, dtype=torch.uint8, device=DEV)
+    scratch = torch.zeros(lib.kg_linear_scratch_bytes(rows, d), dtype=torch.uint8, device=DEV)
     wqkv_d, x_d, nw_d = pack_qkv(wq.to(DEV), wk.to(DEV), wv.to(DEV), H, Hkv, hd), x.to(DEV), nw.to(DEV)   # keep alive
     _lib.check(lib.kg_qkv_rope_append(code, vp(wqkv_d), d, H, Hkv, hd, vp(x_d), rows, pos0,
                                       vp(nw_d), 1e-6, vp(cos), vp(sin), vp(q), vp(kc), vp(vc), t_max, vt, vp(scratch), 0, 0, stream()),

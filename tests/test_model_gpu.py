@@ -26,6 +26,7 @@ from oracle import kangaroo_oracle as ko
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "*.npz")) if not p.endswith("layers.npz"))
 LOGIT_TOL = 1e-2
+KG_STEPS_MAX = 7           # a round writes at most steps + 1 = 7 tokens
 
 
 def load_case(path):
@@ -40,8 +41,46 @@ def oracle_model(shape_name, base, adapter, L, round_to=None):
     return ko.OracleKangarooModel(ko.Shape(**get_shape(shape_name).to_dict()), base, adapter, L, round_to)
 
 
-def explain_divergence(dev_ids, ref_ids, T0, omodel):
-    """First differing position must be a near-tie for the oracle under teacher forcing."""
+# ---- near-tie escapes ------------------------------------------------------------------------------
+# A 16-bit device path and an fp32 reference cannot agree bit for bit when two candidates are closer than the
+# device's rounding noise.  Every place where a test lets such a difference pass is RECORDED (case, prompt, kind,
+# position) and must be listed in tests/golden/EXPLAINED.json; a difference that is not on that list fails the
+# test, and test_zz_explained_cases_equal_the_allow_list fails when the list names a case that did not occur.
+# KG_EXPLAINED_UPDATE=1 skips the membership check so that a new list can be written from
+# gpurun_out/EXPLAINED_run.json after a kernel change (every entry still has to pass its near-tie test).
+EXPLAINED_PATH = os.path.join(GOLD, "EXPLAINED.json")
+_ALLOW = json.load(open(EXPLAINED_PATH)) if os.path.exists(EXPLAINED_PATH) else []
+_ALLOW_KEYS = {(e["case"], e["prompt"], e["kind"], e["position"]) for e in _ALLOW}
+_SEEN = []
+
+
+def record_explained(case, prompt, kind, position, detail):
+    key = (case, str(prompt), kind, int(position))
+    _SEEN.append({"case": key[0], "prompt": key[1], "kind": key[2], "position": key[3], "detail": detail})
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "EXPLAINED_run.json"), "w") as f:
+            json.dump(_SEEN, f, indent=1)
+    except OSError:
+        pass
+    if not os.environ.get("KG_EXPLAINED_UPDATE"):
+        assert key in _ALLOW_KEYS, f"near-tie escape not on the allow-list: {key}: {detail}"
+
+
+def p_tol(p, scale, tol=None):
+    """How far a softmax maximum p can move under the rounding noise of stored 16-bit logits.  The noise is
+    taken as a fifth of the parity tolerance times the row's max-abs (2e-3 x max-abs for fp16: the kernel tests
+    bound a stored logit's error by 4e-3 of max-abs, typical errors are a quarter of that; at max-abs 34 that
+    is two fp16 spacings of the top logit), and d p / d l = p (1 - p) for the top logit, the opposite sign for
+    the rest, hence the factor 2."""
+    return 2.0 * p * (1.0 - p) * (0.2 * (tol or LOGIT_TOL)) * scale
+
+
+def explain_divergence(dev_ids, ref_ids, T0, omodel, ref_is_oracle=True, tol=LOGIT_TOL):
+    """First differing position must be a near-tie for the oracle under teacher forcing.  Returns
+    (position, detail) or None when the sequences agree on their common length.  ref_is_oracle: ref_ids came
+    from the fp32 reference / oracle, whose token there must then be the oracle's argmax."""
     n = min(len(dev_ids), len(ref_ids))
     first = next((i for i in range(n) if dev_ids[i] != ref_ids[i]), None)
     if first is None:
@@ -52,36 +91,100 @@ def explain_divergence(dev_ids, ref_ids, T0, omodel):
     best = float(row.max())
     gap = best - float(row[dev_ids[first]])
     scale = float(row.abs().max())
-    assert gap <= LOGIT_TOL * scale, f"divergence at {first} is not a near-tie: gap {gap} vs scale {scale}"
-    return first
+    if ref_is_oracle:
+        assert int(row.argmax()) == ref_ids[first], "the reference's own token is not the oracle's argmax on that prefix"
+    else:
+        assert best - float(row[ref_ids[first]]) <= tol * scale
+    assert gap <= tol * scale, f"divergence at {first} is not a near-tie: gap {gap} vs scale {scale}"
+    return first, f"oracle top-1 minus device token's logit {gap:.4g} of max-abs {scale:.4g}"
 
 
-P_TOL = 3e-2      # |p_max - threshold| below this is a confidence near-tie in 16-bit logits
-
-
-def explain_round_divergence(dev_accept, dev_draft, ref_accept, ref_draft, ref_pmax, ref_draft_logits, thr):
-    """Accept / draft-length lists differ although the output ids agree: the first
-    differing round must contain a draft step whose confidence sits within P_TOL of the
-    threshold, or whose draft logits have a top-2 gap within LOGIT_TOL of their scale
-    (the draft picked the other of two tied tokens; the verify pass repairs it)."""
+def explain_round_divergence(dev_ids, dev_accept, dev_draft, ref_ids, ref_accept, ref_draft, T0, ref_pmax, ref_draft_logits,
+                             ref_verify_logits, thr, top_k=1, top_p=None, temperature=1.0, tol=LOGIT_TOL):
+    """Rounds are walked in step; up to the first round whose (accept, draft, tokens) differ both loops were in
+    the same state, so the reference's logits of THAT round are the fp32 values of what the device computed in
+    16 bits.  The round must hold a decision that sits within rounding noise: a draft confidence next to the
+    threshold, a draft or verify argmax with a top-2 gap inside the tolerance, or (non-greedy rules) a drafted
+    token next to the rule's boundary.  Returns (position of the round's first token, detail)."""
     da, ra = list(dev_accept[1:]), list(ref_accept[1:])
-    r = next((i for i in range(min(len(da), len(ra))) if (da[i], dev_draft[i]) != (ra[i], ref_draft[i])), None)
-    assert r is not None, "lists differ only in length"
-    i0 = int(sum(ref_draft[:r]))
-    for j in range(int(ref_draft[r])):
-        p = float(ref_pmax[i0 + j])
-        if abs(p - thr) <= P_TOL:
-            return f"round {r} step {j}: p_max {p:.4f} vs threshold {thr}"
-        row = torch.as_tensor(ref_draft_logits[i0 + j]).float()
-        top2 = row.topk(2).values
-        if float(top2[0] - top2[1]) <= LOGIT_TOL * float(row.abs().max()):
-            return f"round {r} step {j}: draft top-2 gap {float(top2[0] - top2[1]):.4f}"
-    raise AssertionError(f"round {r}: accept/draft {da[r]}/{dev_draft[r]} vs reference {ra[r]}/{ref_draft[r]} with no near-tie in that round")
+    s, i_d, i_v = T0, 0, 0
+    for r in range(min(len(da), len(ra))):
+        q = int(ref_draft[r]) + 1
+        if (da[r], dev_draft[r]) == (ra[r], ref_draft[r]) and dev_ids[s + 1:s + 1 + ra[r]] == ref_ids[s + 1:s + 1 + ra[r]]:
+            s += ra[r]; i_d += q - 1; i_v += q
+            continue
+        for j in range(q - 1):
+            row = torch.as_tensor(ref_draft_logits[i_d + j]).float()
+            scale = float(row.abs().max())
+            p = float(ref_pmax[i_d + j])
+            if abs(p - thr) <= p_tol(p, scale, tol):
+                return s, f"round {r} step {j}: p_max {p:.4f} vs threshold {thr} (tolerance {p_tol(p, scale, tol):.4f})"
+            top2 = row.topk(2).values
+            if float(top2[0] - top2[1]) <= tol * scale:
+                return s, f"round {r} step {j}: draft top-2 gap {float(top2[0] - top2[1]):.4g} of {scale:.4g}"
+        for i in range(q):
+            row = torch.as_tensor(ref_verify_logits[i_v + i]).float()
+            scale = float(row.abs().max())
+            srt = row.sort(descending=True).values
+            if float(srt[0] - srt[1]) <= tol * scale:
+                return s, f"round {r} verify row {i}: top-2 gap {float(srt[0] - srt[1]):.4g} of {scale:.4g}"
+            if top_k > 1 and float(srt[top_k - 1] - srt[top_k]) <= tol * scale:
+                return s, f"round {r} verify row {i}: gap at the top-{top_k} boundary {float(srt[top_k - 1] - srt[top_k]):.4g} of {scale:.4g}"
+            if top_p is not None:
+                pr = torch.softmax(row / temperature, -1).sort(descending=True).values
+                cum = pr.cumsum(-1)
+                near = (cum - top_p).abs().min()
+                if float(near) <= tol * scale / temperature:       # a probability mass moves by at most the logit error
+                    return s, f"round {r} verify row {i}: cumulative mass {float(near):.4g} from top_p {top_p}"
+        raise AssertionError(f"round {r} (start {s}): accept/draft {da[r]}/{dev_draft[r]} vs reference {ra[r]}/{ref_draft[r]} with no near-tie in that round")
+    raise AssertionError("lists differ only in length")
+
+
+def check_against_reference(case, prompt, dev, ref, T0, ref_pmax, ref_draft_logits, ref_verify_logits, thr, omodel_fn, rule=None, tol=LOGIT_TOL):
+    """dev / ref = (ids, accept_list, draft_lengths, new_token, idx).  Bit-exact, or an allow-listed near-tie;
+    whatever precedes the first difference is still compared exactly."""
+    d_ids, d_acc, d_dr, d_new, d_idx = dev
+    r_ids, r_acc, r_dr, r_new, r_idx = ref
+    rule = rule or {}
+    if d_ids == r_ids and d_acc == r_acc and d_dr == r_dr:
+        assert (d_new, d_idx) == (r_new, r_idx)
+        return
+    # first round whose (accept, draft, tokens) differ: both loops entered it in the same state
+    s0 = T0
+    for a, c, b, d in zip(d_acc[1:], d_dr, r_acc[1:], r_dr):
+        if (a, c) != (b, d) or d_ids[s0 + 1:s0 + 1 + b] != r_ids[s0 + 1:s0 + 1 + b]:
+            break
+        s0 += b
+    assert d_ids[:s0 + 1] == r_ids[:s0 + 1]          # everything up to that round's start agrees exactly
+    n = min(len(d_ids), len(r_ids))
+    first = next((i for i in range(n) if d_ids[i] != r_ids[i]), None)
+    if first is not None and not rule and first <= s0 + 1 + max(KG_STEPS_MAX, 0):
+        # a token of that very round differs: under greedy acceptance both tokens are verify argmaxes of the same
+        # prefix, so the teacher-forced oracle row decides whether it was a near-tie
+        pos, why = explain_divergence(d_ids, r_ids, T0, omodel_fn(), tol=tol)
+        record_explained(case, prompt, "ids", pos, why)
+        return
+    pos, why = explain_round_divergence(d_ids, d_acc, d_dr, r_ids, r_acc, r_dr, T0, ref_pmax, ref_draft_logits, ref_verify_logits, thr,
+                                        top_k=rule.get("hyper_k", 1) if rule.get("do_sample") == "top_k" else 1,
+                                        top_p=rule.get("hyper_p") if rule.get("do_sample") == "top_p" else None,
+                                        temperature=rule.get("temperature", 1.0), tol=tol)
+    assert pos == s0
+    record_explained(case, prompt, "round", pos, why)
+    if first is not None and not rule:
+        # the rounds parted on a near-tie first (same tokens, other boundaries) and a token differs later on
+        pos, why = explain_divergence(d_ids, r_ids, T0, omodel_fn(), tol=tol)
+        record_explained(case, prompt, "ids", pos, why)
+
+
+def _golden_ref(z, pi):
+    return (z[f"p{pi}/output_ids"].tolist(), z[f"p{pi}/accept_length_list"].tolist(), z[f"p{pi}/draft_lengths"].tolist(),
+            int(z[f"p{pi}/new_token"]), int(z[f"p{pi}/idx"]))
 
 
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
 def test_fused_loop_matches_reference_golden(path):
     z, meta, base, adapter = load_case(path)
+    case = os.path.basename(path)[:-4]
     shape = get_shape(meta["shape"])
     model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, meta["exit_layer"])
     top_k = meta.get("accept_top_k", 1)          # > 1: top-k verification (inference_kangaroo_MTBench.py:377-389)
@@ -92,35 +195,16 @@ def test_fused_loop_matches_reference_golden(path):
         ids = torch.from_numpy(z[f"p{pi}/input_ids"]).cuda()
         out, new_tok, idx, accept, st = kangaroo_forward(ids, model, meta["eos"], meta["max_new_tokens"], EARLY_STOP_LAYER=meta["exit_layer"],
                                                          SPECULATIVE_DECODING_STEPS=meta["steps"], threshold=meta["threshold"], return_stats=True, **rule)
-        gold = z[f"p{pi}/output_ids"].tolist()
-        if rule:
-            # not lossless by design, and a divergence could also be a near-tie at the k-th logit:
-            # these fixtures are required to reproduce exactly
-            assert out[0] == gold
-            ref_accept, ref_draft = z[f"p{pi}/accept_length_list"].tolist(), z[f"p{pi}/draft_lengths"].tolist()
-            if accept != ref_accept or st.draft_lengths != ref_draft:
-                # same ids, different round boundaries: a draft confidence within 16-bit noise of the threshold
-                why = explain_round_divergence(accept, st.draft_lengths, ref_accept, ref_draft, z[f"p{pi}/p_max"], z[f"p{pi}/draft_logits"], meta["threshold"])
-                print(f"EXPLAINED {os.path.basename(path)} p{pi}: {why}")
-            else:
-                assert (new_tok, idx) == (int(z[f"p{pi}/new_token"]), int(z[f"p{pi}/idx"]))
-            continue
-        if out[0] != gold:
-            om = oracle_model(meta["shape"], base, adapter, meta["exit_layer"])
-            at = explain_divergence(out[0], gold, ids.shape[1], om)
-            print(f"EXPLAINED {os.path.basename(path)} p{pi}: ids diverge at {at} on an argmax near-tie")
-            continue
-        ref_accept, ref_draft = z[f"p{pi}/accept_length_list"].tolist(), z[f"p{pi}/draft_lengths"].tolist()
-        if accept != ref_accept or st.draft_lengths != ref_draft:
-            why = explain_round_divergence(accept, st.draft_lengths, ref_accept, ref_draft, z[f"p{pi}/p_max"], z[f"p{pi}/draft_logits"], meta["threshold"])
-            print(f"EXPLAINED {os.path.basename(path)} p{pi}: {why}")
-        else:
-            assert new_tok == int(z[f"p{pi}/new_token"])
-            assert idx == int(z[f"p{pi}/idx"])
-        # lossless: plain greedy decoding on the same kernels gives the same ids
-        van = vanilla_forward(ids, model, meta["eos"], new_tok)[0][0]
-        assert van == out[0][:len(van)]
-        assert len(van) == len(out[0]) or van[-1] == meta["eos"]
+        # verify logits are stored per round as one [q, V] block per row
+        check_against_reference(case, f"p{pi}", (out[0], accept, st.draft_lengths, new_tok, idx), _golden_ref(z, pi), ids.shape[1],
+                                z[f"p{pi}/p_max"], z[f"p{pi}/draft_logits"], z[f"p{pi}/verify_logits"], meta["threshold"],
+                                lambda: oracle_model(meta["shape"], base, adapter, meta["exit_layer"]), rule)
+        if not rule:
+            # lossless on the device whatever the comparison with the reference said: plain greedy decoding on
+            # the same kernels gives the same ids
+            van = vanilla_forward(ids, model, meta["eos"], new_tok)[0][0]
+            assert van == out[0][:len(van)]
+            assert len(van) == len(out[0]) or van[-1] == meta["eos"]
 
 
 @pytest.mark.parametrize("path", CASES[:3], ids=[os.path.basename(p)[:-4] for p in CASES[:3]])
@@ -135,15 +219,14 @@ def test_stepwise_interface_matches_golden(path):
         tr = {}
         out, new_tok, idx, accept = kangaroo_forward_stepwise(ids, model, meta["eos"], meta["max_new_tokens"], EARLY_STOP_LAYER=meta["exit_layer"],
                                                               SPECULATIVE_DECODING_STEPS=meta["steps"], threshold=meta["threshold"], trace=tr)
-        gold = z[f"p{pi}/output_ids"].tolist()
-        if out[0] != gold:
-            explain_divergence(out[0], gold, ids.shape[1], oracle_model(meta["shape"], base, adapter, meta["exit_layer"]))
-            continue
-        ref_accept, ref_draft = z[f"p{pi}/accept_length_list"].tolist(), z[f"p{pi}/draft_lengths"].tolist()
-        if accept != ref_accept or tr["draft_lengths"] != ref_draft:
-            explain_round_divergence(accept, tr["draft_lengths"], ref_accept, ref_draft, z[f"p{pi}/p_max"], z[f"p{pi}/draft_logits"], meta["threshold"])
-        else:
-            np.testing.assert_allclose(np.asarray(tr.get("p_max", [])), z[f"p{pi}/p_max"], atol=P_TOL)
+        check_against_reference("stepwise:" + os.path.basename(path)[:-4], f"p{pi}", (out[0], accept, tr["draft_lengths"], new_tok, idx), _golden_ref(z, pi),
+                                ids.shape[1], z[f"p{pi}/p_max"], z[f"p{pi}/draft_logits"], z[f"p{pi}/verify_logits"], meta["threshold"],
+                                lambda: oracle_model(meta["shape"], base, adapter, meta["exit_layer"]))
+        if (out[0], accept, tr["draft_lengths"]) == _golden_ref(z, pi)[:3]:
+            ref_p = z[f"p{pi}/p_max"]
+            scales = np.abs(z[f"p{pi}/draft_logits"]).max(axis=-1) if len(ref_p) else np.zeros(0)
+            tol = np.maximum(1e-3, 2 * ref_p * (1 - ref_p) * 0.5 * LOGIT_TOL * scales)
+            assert np.all(np.abs(np.asarray(tr.get("p_max", [])) - ref_p) <= tol)
 
 
 def test_logits_against_golden():
@@ -189,15 +272,9 @@ def test_against_live_oracle(shape_name, L, recipe, seed):
         tr = ko.Trace()
         ref = ko.kangaroo_forward(ids, om, 2, 48, EARLY_STOP_LAYER=L, trace=tr, keep_logits=True)
         out, new_tok, idx, accept, st = kangaroo_forward(ids.cuda(), model, 2, 48, EARLY_STOP_LAYER=L, return_stats=True)
-        if out[0] != ref[0][0]:
-            om2 = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), base, adapter, L)
-            explain_divergence(out[0], ref[0][0], plen, om2)
-            continue
-        if accept != ref[3] or st.draft_lengths != tr.draft_lengths:
-            why = explain_round_divergence(accept, st.draft_lengths, ref[3], tr.draft_lengths, tr.p_max, tr.draft_logits, 0.6)
-            print(f"EXPLAINED {shape_name} plen {plen}: {why}")
-        else:
-            assert (new_tok, idx) == (ref[1], ref[2])
+        check_against_reference(f"live:{shape_name}:L{L}:seed{seed}", f"plen{plen}", (out[0], accept, st.draft_lengths, new_tok, idx),
+                                (ref[0][0], ref[3], tr.draft_lengths, ref[1], ref[2]), plen, tr.p_max, tr.draft_logits, torch.cat(tr.verify_logits, 0), 0.6,
+                                lambda: ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), base, adapter, L))
         van = vanilla_forward(ids.cuda(), model, 2, new_tok)[0][0]
         assert van == out[0][:len(van)]
 
@@ -220,12 +297,9 @@ def test_non_greedy_rules_against_live_oracle(rule):
     tr = ko.Trace()
     ref = ko.kangaroo_forward(ids, om, 2, 40, EARLY_STOP_LAYER=2, trace=tr, keep_logits=True, **okw)
     out, new_tok, idx, accept, st = kangaroo_forward(ids.cuda(), model, 2, 40, EARLY_STOP_LAYER=2, return_stats=True, **rule)
-    assert out[0] == ref[0][0]
-    if accept != ref[3] or st.draft_lengths != tr.draft_lengths:
-        why = explain_round_divergence(accept, st.draft_lengths, ref[3], tr.draft_lengths, tr.p_max, tr.draft_logits, 0.6)
-        print(f"EXPLAINED {rule}: {why}")
-    else:
-        assert (new_tok, idx) == (ref[1], ref[2])
+    check_against_reference(f"live-rule:{rule['do_sample']}", "seed31", (out[0], accept, st.draft_lengths, new_tok, idx),
+                            (ref[0][0], ref[3], tr.draft_lengths, ref[1], ref[2]), 12, tr.p_max, tr.draft_logits, torch.cat(tr.verify_logits, 0), 0.6,
+                            None, rule)
     # the rule was applied, and is more permissive than greedy matching
     greedy = kangaroo_forward(ids.cuda(), model, 2, 40, EARLY_STOP_LAYER=2)
     assert sum(accept) / len(accept) >= sum(greedy[3]) / len(greedy[3])
@@ -275,10 +349,8 @@ def test_eos_stop_max_length_and_shortest_prompt_against_live_oracle():
     tr = ko.Trace()
     ref = ko.kangaroo_forward(one, om(), -1, 24, EARLY_STOP_LAYER=L, trace=tr, keep_logits=True)
     out = kangaroo_forward(one.cuda(), model, -1, 24, EARLY_STOP_LAYER=L, return_stats=True)
-    assert out[0] == ref[0]
-    if out[:4] != ref:
-        why = explain_round_divergence(out[3], out[4].draft_lengths, ref[3], tr.draft_lengths, tr.p_max, tr.draft_logits, 0.6)
-        print(f"EXPLAINED one-token prompt: {why}")
+    check_against_reference("one-token-prompt", "p0", (out[0][0], out[3], out[4].draft_lengths, out[1], out[2]),
+                            (ref[0][0], ref[3], tr.draft_lengths, ref[1], ref[2]), 1, tr.p_max, tr.draft_logits, torch.cat(tr.verify_logits, 0), 0.6, om)
 
 
 def test_constructor_from_checkpoint_dirs_and_eval_harness(tmp_path):
@@ -330,7 +402,8 @@ def test_vanilla_gemv_mode_agrees_up_to_near_ties():
     model.engine.set_tuning(vanilla_gemv=1)
     assert len(gemv) == len(std)
     if gemv != std:
-        explain_divergence(gemv, std, 14, oracle_model("small", base, adapter, 2))
+        pos, why = explain_divergence(gemv, std, 14, oracle_model("small", base, adapter, 2), ref_is_oracle=False)
+        record_explained("vanilla-gemv-vs-verify-arithmetic", "seed41", "ids", pos, why)
     assert vanilla_forward(ids, model, -1, 64)[0][0] == std
 
 
@@ -391,7 +464,8 @@ def test_bf16_runs_and_is_lossless():
     van = vanilla_forward(ids, model, 2, new_tok)[0][0]
     om = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), base, adapter, 2)
     if van != out[0][:len(van)]:
-        explain_divergence(out[0], van, 17, om)
+        pos, why = explain_divergence(out[0], van, 17, om, ref_is_oracle=False)
+        record_explained("bf16-kangaroo-vs-vanilla", "seed3", "ids", pos, why)
     assert max(accept) <= 7 and min(accept) >= 1 and sum(accept[1:]) == new_tok - 1
 
 
@@ -478,18 +552,98 @@ def test_gemm_prefill_matches_chunked_prefill(shape_name):
 
 
 def test_full_size_7b_losslessness_and_determinism():
-    """At the benchmark's size (Vicuna-7B shape, exit layer 2, 6 draft steps, threshold 0.6) no CPU
-    oracle finishes in seconds; the size-independent properties are checked instead: Kangaroo's
-    output equals plain greedy decoding on the same kernels token for token, accept lengths add up
-    to the new tokens, every round accepts between 1 and steps+1 tokens and never more than it
-    drafted + 1, and a second run reproduces the first bit for bit."""
-    shape = get_shape("vicuna-7b")
-    base, adapter = synth_state_dicts(shape, 2, seed=0, dtype=torch.float16, recipe=Recipe.agreeable(0.08, 10.0), device="cuda")
-    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, 2, release_source=True)
+    """At the benchmark's size (Vicuna-7B shape, exit layer 2, 6 draft steps, threshold 0.6) the fp32 CPU
+    oracle takes minutes per prompt; beside the short oracle comparison of
+    test_7b_shape_parity_with_the_oracle_is_a_near_tie_or_exact, the size-independent properties are checked:
+    Kangaroo's output equals plain greedy decoding on the same kernels token for token, accept lengths add up
+    to the new tokens, every round accepts between 1 and steps+1 tokens and never more than it drafted + 1,
+    and a second run reproduces the first bit for bit."""
+    _losslessness_and_determinism("vicuna-7b", 2, torch.float16, ((23, 160), (300, 96)))
+
+
+@pytest.mark.parametrize("path", [CASES[1], CASES[2], next(p for p in CASES if "L3" in p)], ids=lambda p: os.path.basename(p)[:-4])
+def test_reference_loop_drives_the_mirror_classes(path):
+    """The reference's own loop, statement for statement (oracle.kangaroo_forward restates
+    evaluation/inference_kangaroo.py:15-129), pointed at the HIP classes instead of the oracle's model: device
+    token buffer and device position_ids on every call (:20-21,29,57,60,63,77,86,89), prefill logits for ALL rows
+    and hidden_states[-1] / [EARLY_STOP_LAYER] (:30-35), `[:, -1:]` slices, `.float()` on the head output (:79,91),
+    cache views read through `.shape[2]` and truncated with `[:, :, :n, :]` (:53,55,87,108-119)."""
+    z, meta, base, adapter = load_case(path)
+    case = "refloop:" + os.path.basename(path)[:-4]
+    shape = get_shape(meta["shape"])
+    L = meta["exit_layer"]
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, L)
+    for pi in range(meta["n_prompts"]):
+        ids = torch.from_numpy(z[f"p{pi}/input_ids"]).cuda()
+        tr = ko.Trace()
+        out, new_tok, idx, accept = ko.kangaroo_forward(ids, model, meta["eos"], meta["max_new_tokens"], EARLY_STOP_LAYER=L,
+                                                        SPECULATIVE_DECODING_STEPS=meta["steps"], threshold=meta["threshold"], trace=tr)
+        check_against_reference(case, f"p{pi}", (out[0], accept, tr.draft_lengths, new_tok, idx), _golden_ref(z, pi), ids.shape[1],
+                                z[f"p{pi}/p_max"], z[f"p{pi}/draft_logits"], z[f"p{pi}/verify_logits"], meta["threshold"],
+                                lambda: oracle_model(meta["shape"], base, adapter, L))
+        # same answer as the fused loop on the same kernels
+        fused = kangaroo_forward(ids, model, meta["eos"], meta["max_new_tokens"], EARLY_STOP_LAYER=L, SPECULATIVE_DECODING_STEPS=meta["steps"], threshold=meta["threshold"])
+        assert fused[0][0] == out[0]
+    # position ids that do not continue the cache are refused, on the device as on the host
+    model.base_model.past_key_values = list(model.base_model(ids, position_ids=torch.arange(ids.shape[1], device="cuda").view(1, -1)).past_key_values)
+    T = ids.shape[1]
+    with pytest.raises(ValueError):
+        model.base_model.forward_draft_or_large_model(in_tokens_small=ids[:, -1:], position_ids=torch.tensor([[T + 1]], device="cuda"))
+    with pytest.raises(ValueError):
+        model.base_model.forward_draft_or_large_model(in_tokens_small=ids[:, -1:], position_ids=torch.tensor([[T - 1]]))
+    with pytest.raises(ValueError):
+        model.adapter_model.forward_early_stop(inputs_embeds=torch.zeros(1, 2, shape.hidden_size, device="cuda", dtype=torch.float16),
+                                               position_ids=torch.tensor([[3, 5]], device="cuda"))
+    with pytest.raises(ValueError):
+        model.base_model(torch.tensor([[3, shape.vocab_size]]).cuda())          # token id beyond the embedding table
+
+
+def _cut(shape, n_layers):
+    return type(shape)(**{**shape.to_dict(), "num_hidden_layers": n_layers})
+
+
+@pytest.mark.parametrize("name,L,n_layers,dtype,tol,recipe", [
+    ("vicuna-13b", 3, 5, torch.float16, LOGIT_TOL, (0.3, 10.0)),       # data/vicuna_13B_config.json:8-21, exit layer 3 (data/ge_data_all_vicuna.py:149-152)
+    ("llama-33b", 2, 4, torch.bfloat16, 3 * LOGIT_TOL, (0.3, 10.0)),   # d 6656 / F 17920 / 52 heads in bf16: the 2-wave o_proj split and bf16 MFMA at real size
+    ("vicuna-7b", 2, 4, torch.float16, LOGIT_TOL, (0.3, 10.0)),
+], ids=["13b-L3-5layers-f16", "33b-4layers-bf16", "7b-4layers-f16"])
+def test_real_layer_shapes_against_live_oracle(name, L, n_layers, dtype, tol, recipe):
+    """The layer shapes of the benchmark configurations with the layer count cut so that the fp32 CPU oracle
+    finishes in seconds: every kernel runs at its real K / N (two-chunk X prologue at d > 4096, the large-K
+    down_proj mode, the o_proj wave splits).  The bf16 case is held to 3e-2 instead of 1e-2: bf16 keeps 8
+    significand bits against fp16's 11, and the oracle it is compared with computes in fp32."""
+    shape = _cut(get_shape(name), n_layers)
+    base, adapter = synth_state_dicts(shape, L, seed=61, dtype=dtype, recipe=Recipe.agreeable(*recipe), device="cuda")
+    model = KangarooModel.from_state_dicts(shape, base, adapter, dtype, L)
+    om = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), {k: v.cpu() for k, v in base.items()}, {k: v.cpu() for k, v in adapter.items()}, L)
+    del base, adapter
+    g = torch.Generator().manual_seed(61)
+    for plen in (11, 37):
+        ids = torch.randint(3, shape.vocab_size, (1, plen), generator=g)
+        tr = ko.Trace()
+        ref = ko.kangaroo_forward(ids, om, 2, 40, EARLY_STOP_LAYER=L, trace=tr, keep_logits=True)
+        out, new_tok, idx, accept, st = kangaroo_forward(ids.cuda(), model, 2, 40, EARLY_STOP_LAYER=L, return_stats=True)
+        check_against_reference(f"shape:{name}:{n_layers}", f"plen{plen}", (out[0], accept, st.draft_lengths, new_tok, idx),
+                                (ref[0][0], ref[3], tr.draft_lengths, ref[1], ref[2]), plen, tr.p_max, tr.draft_logits, torch.cat(tr.verify_logits, 0), 0.6,
+                                lambda: om, tol=tol)
+        # logits of the prompt's last row: device vs oracle, within the stated tolerance of the row's max-abs
+        dev_row = model.base_model(ids.cuda(), logits_rows="last").logits[0, -1].float().cpu()
+        ref_row = om.base_model(ids).logits[0, -1]
+        assert float((dev_row - ref_row).abs().max()) <= tol * float(ref_row.abs().max())
+        van = vanilla_forward(ids.cuda(), model, 2, new_tok)[0][0]
+        assert van == out[0][:len(van)]
+    del model, om
+    torch.cuda.empty_cache()
+
+
+def _losslessness_and_determinism(name, L, dtype, prompts):
+    shape = get_shape(name)
+    base, adapter = synth_state_dicts(shape, L, seed=0, dtype=dtype, recipe=Recipe.agreeable(0.08, 10.0), device="cuda")
+    model = KangarooModel.from_state_dicts(shape, base, adapter, dtype, L, release_source=True)
     del base, adapter
     eng = model.engine
     g = torch.Generator().manual_seed(77)
-    for plen, new in ((23, 160), (300, 96)):
+    for plen, new in prompts:
         ids = torch.randint(3, shape.vocab_size, (plen,), generator=g)
         out, st = eng.generate(ids, new, mode="kangaroo")
         out2, st2 = eng.generate(ids, new, mode="kangaroo")
@@ -503,6 +657,39 @@ def test_full_size_7b_losslessness_and_determinism():
         assert new - 1 - 6 <= st.new_tokens <= new
     del model, eng
     torch.cuda.empty_cache()
+
+
+def test_full_size_13b_losslessness_and_determinism():
+    """Vicuna-13B shape, all 40 layers, exit layer 3 (the third benchmark configuration): the size-independent
+    properties of test_full_size_7b_losslessness_and_determinism."""
+    _losslessness_and_determinism("vicuna-13b", 3, torch.float16, ((23, 120), (300, 72)))
+
+
+def test_7b_shape_parity_with_the_oracle_is_a_near_tie_or_exact():
+    """The benchmark's own model (Vicuna-7B shape, 32 layers, bench.py's weight recipe) against the fp32 CPU
+    oracle on the same weights: 2 prompts x 24 new tokens.  Whatever differs first (a token, or an accept /
+    draft length) is traced by oracle/parity.py and has to be a near-tie within 1e-2 of the row's max-abs,
+    with the device's logits row for the same prefix within that tolerance of the oracle's."""
+    from oracle import parity
+    shape = get_shape("vicuna-7b")
+    L = 2
+    base, adapter = synth_state_dicts(shape, L, seed=0, dtype=torch.float16, recipe=Recipe.agreeable(0.08, 10.0), device="cuda")
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, L)
+    om = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), {k: v.cpu() for k, v in base.items()}, {k: v.cpu() for k, v in adapter.items()}, L)
+    del base, adapter
+    for seed, plen in ((7, 32), (8, 20)):
+        ids = torch.randint(3, shape.vocab_size, (1, plen), generator=torch.Generator().manual_seed(seed))
+        tr = ko.Trace()
+        ref = ko.kangaroo_forward(ids, om, -1, 24, EARLY_STOP_LAYER=L, trace=tr, keep_logits=True)
+        out, new_tok, idx, accept, st = kangaroo_forward(ids.cuda(), model, -1, 24, EARLY_STOP_LAYER=L, return_stats=True)
+        rec = parity.first_difference(out[0], accept, st.draft_lengths, ref[0][0], ref[3], tr.draft_lengths, plen, om, tr.p_max, tr.draft_logits, 0.6,
+                                      dev_logits_row=lambda pre: model.base_model(torch.tensor([pre]).cuda(), logits_rows="last").logits[0, -1])
+        assert rec["kind"] == "none" or rec["within_tol"], rec
+        if rec["kind"] != "none":
+            record_explained("7b-bench-weights", f"seed{seed}", rec["kind"], rec.get("position", rec.get("round", -1)), json.dumps(rec))
+    del model, om
+    torch.cuda.empty_cache()
+
 
 
 def test_attention_geometry_does_not_change_results():
@@ -524,3 +711,18 @@ def test_attention_geometry_does_not_change_results():
         else:
             assert (out, st.accept_lengths, st.draft_lengths) == ref, (blocks, teams)
     eng.set_tuning(attn_blocks=16, attn_teams=1)
+
+
+def test_zz_explained_cases_equal_the_allow_list():
+    """Runs last in this file: the near-tie escapes taken in this process are exactly the committed list (a new
+    one already failed where it occurred; a listed one that no longer occurs must be struck from the list)."""
+    ran = {(e["case"], e["prompt"], e["kind"], e["position"]) for e in _SEEN}
+    if os.environ.get("KG_EXPLAINED_UPDATE"):
+        pytest.skip("allow-list is being regenerated")
+    if not ran and not _ALLOW_KEYS:
+        return
+    # only meaningful when the whole file ran in this process
+    import sys
+    if any(a.startswith("tests/test_model_gpu.py::") or "-k" == a for a in sys.argv):
+        pytest.skip("partial run")
+    assert ran == _ALLOW_KEYS, f"not on the list: {sorted(ran - _ALLOW_KEYS)}; listed but did not occur: {sorted(_ALLOW_KEYS - ran)}"
