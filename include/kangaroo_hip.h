@@ -153,6 +153,19 @@ int kg_draft_step(int dtype, const void* logits, int vocab, int step, int steps,
                   void* scratch /* device, kg_control_scratch_bytes() */, void* stream);
 size_t kg_control_scratch_bytes(void);
 
+/* kg_head without a scratch argument, for callers that cannot allocate device memory (code under HIP graph
+ * capture, serving loops and harnesses that forbid hipMalloc).  No counterpart in the reference.  The
+ * per-block softmax records and the pass parameters live in a device array built into the library (1 MiB
+ * + 256 B per GPU, held until the process ends), so vocab is limited to kg_head_noalloc_max_vocab() = 65536;
+ * larger values are refused with -1.  Neither call allocates or frees.  Calls on one GPU share that array:
+ * calls that overlap on one GPU (different streams or threads) race; calls on one stream do not.
+ * kg_head_noalloc_init() looks the array's address up for the current device (done on first use otherwise). */
+int kg_head_noalloc_init(void);
+size_t kg_head_noalloc_max_vocab(void);
+int kg_head_noalloc(int dtype, const void* w_packed, int vocab, int d, const void* x, int n_rows,
+                    int prologue, const void* norm_w, float eps,
+                    void* logits_out, int* argmax_out, float* pmax_out, int nblocks, int nwaves, void* stream);
+
 /* ---- model-level entry points ---------------------------------------------------- */
 
 size_t kg_workspace_bytes(const kg_shape* shape, int t_max);

@@ -57,6 +57,9 @@ SYMBOLS = {
     "kg_accept": (_I, [_I, _VP, _I, _I, C.POINTER(C.c_int32), _I, _I, _I, _I, _F, _F, _I, _I, _I, C.POINTER(C.c_int32), _VP, _VP]),
     "kg_draft_step": (_I, [_I, _VP, _I, _I, _I, _D, _I, _I, _I, C.POINTER(C.c_int32), _VP, _VP]),
     "kg_control_scratch_bytes": (_SZ, []),
+    "kg_head_noalloc_init": (_I, []),
+    "kg_head_noalloc_max_vocab": (_SZ, []),
+    "kg_head_noalloc": (_I, [_I, _VP, _I, _I, _VP, _I, _I, _VP, _F, _VP, _VP, _VP, _I, _I, _VP]),
     "kg_workspace_bytes": (_SZ, [C.POINTER(KgShape), _I]),
     "kg_session_create": (_I, [C.POINTER(KgShape), C.POINTER(KgWeights), C.POINTER(KgBuffers), C.POINTER(_VP)]),
     "kg_session_destroy": (_I, [_VP]),

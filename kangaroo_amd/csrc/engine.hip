@@ -1217,3 +1217,40 @@ extern "C" int kg_draft_step(int dtype, const void* logits, int vocab, int step,
     return 0;
 }
 
+// ---------------------------------------------------------------------------------
+// kg_head for callers that may not allocate: the partial records and the pass parameters live in a
+// file-scope device array instead of a caller-provided scratch buffer
+// ---------------------------------------------------------------------------------
+#define KG_NOALLOC_MAX_VOCAB 65536
+#define KG_NOALLOC_BYTES (256 + (size_t)KG_MAX_ROWS * (KG_NOALLOC_MAX_VOCAB / 16) * 4 * sizeof(float))
+static __device__ __align__(256) unsigned char kg_noalloc_scratch[KG_NOALLOC_BYTES];
+static void* g_noalloc_ptr[64];          // per device: the array's device address (every GPU holds its own copy)
+
+extern "C" size_t kg_head_noalloc_max_vocab(void) { return KG_NOALLOC_MAX_VOCAB; }
+
+extern "C" int kg_head_noalloc_init(void) {
+    g_err.clear();
+    int dev = 0;
+    KG_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(-1, "device ordinal beyond 63");
+    if (!g_noalloc_ptr[dev]) {
+        void* p = nullptr;
+        KG_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(kg_noalloc_scratch)));
+        g_noalloc_ptr[dev] = p;
+    }
+    kg_init_once();
+    return 0;
+}
+
+extern "C" int kg_head_noalloc(int dtype, const void* w_packed, int vocab, int d, const void* x, int n_rows,
+                               int prologue, const void* norm_w, float eps,
+                               void* logits_out, int* argmax_out, float* pmax_out, int nblocks, int nwaves, void* stream) {
+    g_err.clear();
+    if (vocab < 1 || vocab > KG_NOALLOC_MAX_VOCAB) return fail(-1, "kg_head_noalloc: vocab exceeds the built-in scratch (65536 rows at most)");
+    int dev = 0;
+    KG_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(-1, "device ordinal beyond 63");
+    if (!g_noalloc_ptr[dev]) KG_TRY(kg_head_noalloc_init());
+    return kg_head(dtype, w_packed, vocab, d, x, n_rows, prologue, norm_w, eps, logits_out, argmax_out, pmax_out,
+                   g_noalloc_ptr[dev], nblocks, nwaves, stream);
+}
