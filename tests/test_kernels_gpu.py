@@ -89,6 +89,54 @@ def test_linear_rmsnorm_resid_silu(dtype, code, rows):
 
 
 @pytest.mark.parametrize("dtype,code", DTYPES, ids=["f16", "bf16"])
+@pytest.mark.parametrize("xscale,gscale", [(1e-3, 0.02), (1e-3, 3.0), (1e3, 0.02), (1e3, 3.0)])
+@pytest.mark.parametrize("rows", [1, 7, 40])
+def test_rmsnorm_prologue_keeps_the_reference_rounding_points(dtype, code, xscale, gscale, rows):
+    """RMSNorm as kangaroo/adapter.py:254-259 orders it: x * rsqrt(mean x^2 + eps) is rounded to the model dtype
+    BEFORE the product with gamma, so activations thousands of times larger than gamma (or embeddings of 1e-3
+    under a gamma of 0.02) neither leave the fp16 range nor sink into its subnormals on the way.  Checked
+    against the oracle's rmsnorm with the same rounding points followed by an fp32 linear."""
+    lib = _lib.lib()
+    d, N = 4096, 256
+    g = torch.Generator().manual_seed(rows + int(gscale * 10))
+    x = (torch.randn(rows, d, generator=g) * xscale).to(dtype)
+    x[:, 5] = x[:, 5] * 10                                   # one outlier channel, as real checkpoints have
+    nw = (gscale * (1 + 0.1 * torch.randn(d, generator=g))).to(dtype)
+    w = (torch.randn(N, d, generator=g) / math.sqrt(d)).to(dtype)
+    assert torch.isfinite(x.float()).all()
+    xn = ko.rmsnorm(x.float(), nw.float(), 1e-6, round_to=dtype)
+    ref = xn @ w.float().T
+    out = torch.full((rows, N), float("nan"), dtype=dtype, device=DEV)
+    wp, xd, nwd = pack_weight(w.to(DEV)), x.to(DEV), nw.to(DEV)
+    scratch = torch.zeros(lib.kg_linear_scratch_bytes(rows, d), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.kg_linear(code, vp(wp), N, d, vp(xd), rows, 1, vp(nwd), 1e-6, 0, None, vp(out), N, vp(scratch), 0, 0, stream()), "kg_linear")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert rel_err(out, ref) < (4e-3 if dtype == torch.float16 else 1.6e-2)
+
+
+@pytest.mark.parametrize("dtype,code", DTYPES, ids=["f16", "bf16"])
+def test_sixteen_row_pass_with_x_streamed_through_wave_slots(dtype, code):
+    """16 rows x K = 4096 with the residual epilogue and 8 waves: X does not fit LDS beside two blocks per CU,
+    so the kernel streams the X columns of each weight batch through per-wave LDS slots (about 149 KiB of
+    dynamic LDS, which needs the opt-in the library sets at start-up)."""
+    lib = _lib.lib()
+    N = K = 4096
+    rows = 16
+    g = torch.Generator().manual_seed(16)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    x = torch.randn(rows, K, generator=g).to(dtype)
+    r = torch.randn(rows, N, generator=g).to(dtype)
+    ref = r.float() + x.float() @ w.float().T
+    wp, xd, rd = pack_weight(w.to(DEV)), x.to(DEV), r.to(DEV)
+    out = torch.full((rows, N), float("nan"), dtype=dtype, device=DEV)
+    scratch = torch.zeros(256, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.kg_linear(code, vp(wp), N, K, vp(xd), rows, 0, None, 0.0, 1, vp(rd), vp(out), N, vp(scratch), 256, 8, stream()), "kg_linear")
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < (4e-3 if dtype == torch.float16 else 1.6e-2)
+
+
+@pytest.mark.parametrize("dtype,code", DTYPES, ids=["f16", "bf16"])
 @pytest.mark.parametrize("H,Hkv,hd", [(4, 2, 16), (8, 8, 32), (4, 1, 64), (32, 32, 128)])
 @pytest.mark.parametrize("rows,pos0", [(1, 0), (1, 37), (2, 5), (7, 130), (16, 0), (16, 48), (40, 3), (64, 100), (100, 20), (128, 100)])
 def test_qkv_rope_attention(dtype, code, H, Hkv, hd, rows, pos0):
