@@ -67,6 +67,21 @@ template <> struct KgT<KG_F16> {
     static __device__ __forceinline__ kg_f4 mfma(kg_u4 a, kg_u4 b, kg_f4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(kg_h8, a), __builtin_bit_cast(kg_h8, b), c, 0, 0, 0);
     }
+    // sum of the squares of 8 stored values (fp32 accumulation)
+    static __device__ __forceinline__ float sum_sq8(kg_u4 v) {
+        float s = dot2(v.x, v.x, 0.f);
+        s = dot2(v.y, v.y, s); s = dot2(v.z, v.z, s);
+        return dot2(v.w, v.w, s);
+    }
+    // gamma * round16(x * rstd), rounded to 16 bits again.  The product of two fp16 values is exact in fp32, so the
+    // packed fp16 multiply (one rounding to nearest even) gives the same bits as multiplying in fp32 and rounding.
+    static __device__ __forceinline__ kg_u4 rms_apply(kg_u4 xv, kg_u4 gv, float rstd) {
+        const kg_h8 x = __builtin_bit_cast(kg_h8, xv), g = __builtin_bit_cast(kg_h8, gv);
+        kg_h8 y;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = (_Float16)((float)x[j] * rstd);
+        return __builtin_bit_cast(kg_u4, y * g);
+    }
 };
 template <> struct KgT<KG_BF16> {
     static __device__ __forceinline__ float to_f(unsigned short u) {
@@ -82,6 +97,18 @@ template <> struct KgT<KG_BF16> {
     static __device__ __forceinline__ kg_f4 mfma(kg_u4 a, kg_u4 b, kg_f4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kg_b8, a), __builtin_bit_cast(kg_b8, b), c, 0, 0, 0);
     }
+    static __device__ __forceinline__ float sum_sq8(kg_u4 v) {
+        float s = dot2(v.x, v.x, 0.f);
+        s = dot2(v.y, v.y, s); s = dot2(v.z, v.z, s);
+        return dot2(v.w, v.w, s);
+    }
+    static __device__ __forceinline__ kg_u4 rms_apply(kg_u4 xv, kg_u4 gv, float rstd) {
+        const kg_us8 x = __builtin_bit_cast(kg_us8, xv), g = __builtin_bit_cast(kg_us8, gv);
+        kg_us8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = from_f(to_f(g[j]) * to_f(from_f(to_f(x[j]) * rstd)));
+        return __builtin_bit_cast(kg_u4, o);
+    }
 };
 
 // round an fp32 value to the storage type and back (the reference's per-op store)
@@ -91,6 +118,21 @@ __device__ __forceinline__ float kg_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+// Wave-wide sum without LDS traffic: four DPP steps leave every lane of a 16-lane row with the row's sum
+// (quad swaps, then the mirror of each half row and of the row), four lane reads and three adds join the rows.
+// Needs all 64 lanes active.  Every lane gets the same bits.
+__device__ __forceinline__ float kg_wave_sum_dpp(float v) {
+#define KG_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false))
+    KG_DPP_ADD(0xB1);       // quad_perm [1,0,3,2]
+    KG_DPP_ADD(0x4E);       // quad_perm [2,3,0,1]
+    KG_DPP_ADD(0x141);      // row_half_mirror
+    KG_DPP_ADD(0x140);      // row_mirror
+#undef KG_DPP_ADD
+    const int vi = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float kg_wave_max(float v) {
 #pragma unroll

@@ -172,43 +172,29 @@ template <int NS> struct ProRegs { kg_u4 v[NS]; kg_u4 gw[2]; };
 // order.  The order of the additions depends on the thread count only, never on the rows riding along.
 template <int RM>
 __device__ __forceinline__ void rms_row_factors(float (&ss)[RM], float* red2, int M, int K, float eps, int lane, int wave, int nwaves) {
+    // red2 holds 8 slots per row whatever the wave count (unused ones are zero), so a row's partial sums
+    // come back as two 16-byte reads
 #pragma unroll
     for (int m = 0; m < RM; ++m) {
         if (m < M) {
-            const float t = kg_wave_sum(ss[m]);
-            if (lane == 0) red2[m * nwaves + wave] = t;
+            const float t = kg_wave_sum_dpp(ss[m]);
+            if (lane == 0) red2[m * 8 + wave] = t;
+            if (lane == 1 && wave == 0) { for (int w = nwaves; w < 8; ++w) red2[m * 8 + w] = 0.f; }
         }
     }
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < RM; ++m) {
         if (m < M) {
-            float tot = 0.f;
-            for (int w = 0; w < nwaves; ++w) tot += red2[m * nwaves + w];
+            const kg_f4 a = *(const kg_f4*)(red2 + m * 8), b = *(const kg_f4*)(red2 + m * 8 + 4);
+            const float tot = (((a[0] + a[1]) + a[2]) + a[3]) + (((b[0] + b[1]) + b[2]) + b[3]);
             ss[m] = rsqrtf(tot / (float)K + eps);
         }
     }
 }
 
-// y = gamma * round16(x * rstd), rounded again: the order of kangaroo/adapter.py:254-259
-template <int DT>
-__device__ __forceinline__ kg_u4 rms_apply(kg_u4 xv, kg_u4 gv, float rstd) {
-    typedef KgT<DT> T;
-    const kg_us8 h = __builtin_bit_cast(kg_us8, xv), g = __builtin_bit_cast(kg_us8, gv);
-    kg_us8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = T::from_f(T::to_f(g[j]) * kg_round<DT>(T::to_f(h[j]) * rstd));
-    return __builtin_bit_cast(kg_u4, o);
-}
-template <int DT>
-__device__ __forceinline__ float sum_sq8(kg_u4 xv) {
-    typedef KgT<DT> T;
-    const kg_us8 h = __builtin_bit_cast(kg_us8, xv);
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const float f = T::to_f(h[j]); s += f * f; }
-    return s;
-}
+template <int DT> __device__ __forceinline__ kg_u4 rms_apply(kg_u4 xv, kg_u4 gv, float rstd) { return KgT<DT>::rms_apply(xv, gv, rstd); }
+template <int DT> __device__ __forceinline__ float sum_sq8(kg_u4 xv) { return KgT<DT>::sum_sq8(xv); }
 
 // K beyond what the register slots hold: two sweeps over the rows (sum of squares, then normalise and store)
 template <int DT, int PRO, int RM, bool COH_LD>
@@ -369,7 +355,7 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
     const int nrg_blk = (G - bid + (int)gridDim.x - 1) / (int)gridDim.x;
     if (idle) {
         // same barrier sequence as the working waves: the norm's (if any), one after the prologue, one per row group
-        if (PRO == PRO_RMSNORM && MODE != MODE_MFMA_GX) __syncthreads();
+        if (PRO == PRO_RMSNORM && MODE == MODE_VEC) __syncthreads();
         __syncthreads();
         for (int i = 0; i < nrg_blk; ++i) __syncthreads();
         gb->arrive();
@@ -391,7 +377,33 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
     const int pro_sets = ((a.K >> 3) <= nthreads) ? 1 : 2;
     const bool pro_fast = (a.K >> 3) <= pro_sets * nthreads && M * pro_sets <= NS;
     ProRegs<NS> pr;
-    if (MODE != MODE_MFMA_GX && pro_fast) {
+    // M-row passes with an RMSNorm: wave w owns rows w, w + nwaves, ... entirely (lane l holds the 16-byte chunks
+    // l, l + 64, ... of the row and of gamma), so a row's sum of squares is ONE wave reduction, the row factor
+    // never leaves the wave, and no barrier or LDS round trip sits between the loads and the normalised row.
+    // A row's arithmetic does not depend on how many rows ride along or on which wave takes it.
+    constexpr bool ROWPRO = (MODE == MODE_MFMA && PRO == PRO_RMSNORM);
+    constexpr int NCM = ROWPRO ? 16 : 1;                       // chunks of a row per lane: K <= 8192
+    kg_u4 rx[NCM], rgm[NCM];
+    const int nchunk_ = a.K >> 3;
+    const __amdgpu_buffer_rsrc_t xrow_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0,
+        ROWPRO ? (int)(((size_t)(M - 1) * a.x_stride + a.K) * 2) : 0, 0x00020000);
+    auto rowpro_load = [&](int row) {
+#pragma unroll
+        for (int i = 0; i < NCM; ++i) {
+            const int c = lane + 64 * i;
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(xrow_rsrc, (row < M && c < nchunk_) ? (unsigned)(((size_t)row * a.x_stride) * 2 + (size_t)c * 16) : 0xFFFFFFFFu,
+                                                          0, COH_LD ? KG_AUX_COH : 0);
+        }
+    };
+    if (ROWPRO) {
+        const __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc((void*)a.norm_w, 0, a.K * 2, 0x00020000);
+        rowpro_load(wave);
+#pragma unroll
+        for (int i = 0; i < NCM; ++i) {
+            const int c = lane + 64 * i;
+            rgm[i] = __builtin_amdgcn_raw_buffer_load_b128(nr, (wave < M && c < nchunk_) ? (unsigned)c * 16u : 0xFFFFFFFFu, 0, 0);
+        }
+    } else if (MODE != MODE_MFMA_GX && pro_fast) {
         if (pro_sets == 1) prologue_load<PRO, NS, 1, COH_LD>(a, pr, M, row_off, tid, nthreads);
         else prologue_load<PRO, NS, 2, COH_LD>(a, pr, M, row_off, tid, nthreads);
     }
@@ -490,7 +502,20 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
             }
         }
     }
-    if (MODE != MODE_MFMA_GX) {
+    if (ROWPRO) {
+        for (int row = wave; row < M; row += nwaves) {          // wave-uniform trip count
+            if (row != wave) rowpro_load(row);
+            float ssq = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCM; ++i) ssq += T::sum_sq8(rx[i]);      // chunks out of range came back as zeros
+            const float rstd = rsqrtf(kg_wave_sum_dpp(ssq) / (float)a.K + a.eps);
+#pragma unroll
+            for (int i = 0; i < NCM; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nchunk_) *(kg_u4*)(xs + (size_t)row * xs_stride + (size_t)c * 16) = T::rms_apply(rx[i], rgm[i], rstd);
+            }
+        }
+    } else if (MODE != MODE_MFMA_GX) {
         if (!pro_fast) prologue_slow<DT, PRO, RM, COH_LD>(a, xs, xs_stride, red2, M, row_off, tid, nthreads, lane, wave, nwaves);
         else if (pro_sets == 1) prologue_finish<DT, PRO, NS, RM, 1>(a, pr, xs, xs_stride, red2, M, tid, nthreads, lane, wave, nwaves);
         else prologue_finish<DT, PRO, NS, RM, 2>(a, pr, xs, xs_stride, red2, M, tid, nthreads, lane, wave, nwaves);

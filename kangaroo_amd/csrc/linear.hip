@@ -50,6 +50,7 @@ int kg_launch_linear(const KgLinArgs& a_in, int dtype, int max_rows, int pro, in
     if (max_rows < 1 || max_rows > KG_MAX_ROWS) return -1;
     if (nwaves < 1 || nwaves > 8) return -1;
     int mode = (max_rows == 1) ? MODE_VEC : MODE_MFMA;
+    if (mode == MODE_MFMA && pro == PRO_RMSNORM && a.K > 8192) return -3;      // a lane holds at most 16 chunks of a row to normalise
     const int G = (a.N + 15) / 16;
     if (nblocks > G) nblocks = G;
     if (nblocks < 1) nblocks = 1;

@@ -76,6 +76,7 @@ size_t kg_persist_plan_linear(KgPhase& p, int max_rows, int nblocks) {
     KgLinArgs& a = p.lin;
     if (a.K % 32 != 0 || a.K <= 0 || a.N <= 0 || max_rows < 2 || max_rows > KG_MAX_ROWS || p.nwaves < 1 || p.nwaves > 8) return 0;
     const int G = (a.N + 15) / 16;
+    if ((p.kind == KG_PH_QKV || p.kind == KG_PH_GATEUP || p.kind == KG_PH_HEAD) && a.K > 8192) return 0;
     size_t side = 0;
     if (p.kind == KG_PH_O || p.kind == KG_PH_DOWN || p.kind == KG_PH_DOWN_GX) side = (size_t)((G + nblocks - 1) / nblocks) * max_rows * 16 * 2;
     if (p.kind == KG_PH_QKV) side = (size_t)max_rows * a.head_dim * 4;
