@@ -137,12 +137,17 @@ size_t kg_head_scratch_bytes(int vocab);
  * :356-374).  Runs the accept kernel of the decode loop (and its rank / nucleus kernels) on a loop state
  * laid out in `scratch`.  logits: device, [q, vocab] stored 16-bit verify logits of rows start_index ..
  * start_index+q-1 (q <= 15); drafted_host: q-1 tokens drafted for positions start_index+1 ..; rule 0 greedy,
- * 1 top-k, 2 top-p on softmax(logits / temperature); steps / max_infer: the loop bound of :46 for out[5].
- * out_host[8] = accept length, token written at the new start index, eos stop flag, new start index,
- * adapter cache length after the rollback, next-round-runs flag, drafted count, rounds done. */
+ * 1 top-k, 2 top-p on softmax(logits / temperature), 3 "typical" (:293-314: a posterior test against
+ * min(epsilon, exp(-entropy) * delta) at every row that ends a run of matches; moves start_index without
+ * writing a token and rebinds the draft threshold, as the reference does); steps / max_infer: the loop bound
+ * of :46 for out[5].  Token slots beyond the drafted ones hold eos_token_id, as the loop's buffer does (:20).
+ * out_host[10] = accept length, token at the new start index, eos / stop flag, new start index,
+ * adapter cache length after the rollback, next-round-runs flag, drafted count, rounds done, and the draft
+ * loop's confidence threshold after the round as the two halves of a double (0.6 going in). */
 int kg_accept(int dtype, const void* logits, int vocab, int q, const int32_t* drafted_host, int start_index,
-              int eos_token_id, int rule, int top_k, float top_p, float temperature, int steps, int max_infer,
-              int adapter_len, int32_t* out_host, void* scratch /* device, kg_control_scratch_bytes() */, void* stream);
+              int eos_token_id, int rule, int top_k, float top_p, float temperature, float epsilon, float delta,
+              int steps, int max_infer, int adapter_len, int32_t* out_host,
+              void* scratch /* device, kg_control_scratch_bytes() */, void* stream);
 /* Control of one draft step on its own (evaluation/inference_kangaroo.py:55-61 adapter rows, :79-83 token and
  * confidence, :74 the second early exit as it will apply to the next step).  logits: device, [1, vocab] draft
  * logits of this step, or NULL to stop after the adapter-row decision.  out_host[8] = adapter rows of the step
@@ -197,7 +202,9 @@ int kg_session_set(kg_session* s, const char* key, int value);
 /* Real-valued settings: "accept_top_p" (0: off; p in (0, 1]: top-p verification, a drafted token is
  * kept while it lies in the pooled nuclei of the round's verify rows,
  * evaluation/inference_kangaroo_MTBench.py:356-374; takes precedence over "accept_top_k") and
- * "temperature" (> 0; divides the verify logits before that rule's softmax, :358).
+ * "temperature" (> 0; divides the verify logits before that rule's softmax, :358); "typical_epsilon" and
+ * "typical_delta" (the posterior threshold min(epsilon, exp(-entropy) * delta) of the typical rule, :279-304,
+ * which the integer key "accept_typical" = 2 switches on and 1 off; it takes precedence over the other two).
  * kg_session_getf returns the value, or -1 for an unknown key. */
 int kg_session_setf(kg_session* s, const char* key, float value);
 float kg_session_getf(kg_session* s, const char* key);

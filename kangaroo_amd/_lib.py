@@ -54,7 +54,7 @@ SYMBOLS = {
     "kg_attention_scratch_bytes": (_SZ, [_I, _I, _I]),
     "kg_head": (_I, [_I, _VP, _I, _I, _VP, _I, _I, _VP, _F, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "kg_head_scratch_bytes": (_SZ, [_I]),
-    "kg_accept": (_I, [_I, _VP, _I, _I, C.POINTER(C.c_int32), _I, _I, _I, _I, _F, _F, _I, _I, _I, C.POINTER(C.c_int32), _VP, _VP]),
+    "kg_accept": (_I, [_I, _VP, _I, _I, C.POINTER(C.c_int32), _I, _I, _I, _I, _F, _F, _F, _F, _I, _I, _I, C.POINTER(C.c_int32), _VP, _VP]),
     "kg_draft_step": (_I, [_I, _VP, _I, _I, _I, _D, _I, _I, _I, C.POINTER(C.c_int32), _VP, _VP]),
     "kg_control_scratch_bytes": (_SZ, []),
     "kg_head_noalloc_init": (_I, []),

@@ -327,7 +327,50 @@ __global__ void kg_topp_member_kernel(KgLoopBufs b, const unsigned short* logits
     }
 }
 
-// accept / reject, cache rollback by length (:91-119).  top_k == 1: the greedy rule of :97; top_k > 1:
+// "Typical" verification (evaluation/inference_kangaroo_MTBench.py:293-314).  For verify row r:
+// p = softmax(logits / temperature), H = -sum p log(p + 1e-5), thr = min(epsilon, exp(-H) * delta);
+// typ[2r] = 1 when max p > thr (:305), typ[2r + 1] = float bits of thr (the reference rebinds its draft
+// threshold to it, :301).  One block per row.
+template <int DT>
+__global__ void kg_typical_kernel(KgLoopBufs b, const unsigned short* logits, int vocab, float temperature, float epsilon, float delta, int* typ) {
+    typedef KgT<DT> T;
+    __shared__ float s_red[4];
+    const int* st = b.state;
+    if (st[KS_ALIVE] == 0) return;
+    const int s = st[KS_START], q = st[KS_END] - s;
+    const int r = blockIdx.x;
+    if (r >= q) return;
+    const unsigned short* row = logits + (size_t)r * vocab;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto block_reduce = [&](float v, bool is_max) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(v, o, 64); v = is_max ? fmaxf(v, t) : v + t; }
+        __syncthreads();
+        if (lane == 0) s_red[wave] = v;
+        __syncthreads();
+        return is_max ? fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])) : (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    };
+    float mx = -INFINITY;
+    for (int v = tid; v < vocab; v += blockDim.x) mx = fmaxf(mx, T::to_f(row[v]) / temperature);
+    mx = block_reduce(mx, true);
+    float z = 0.f;
+    for (int v = tid; v < vocab; v += blockDim.x) z += expf(T::to_f(row[v]) / temperature - mx);
+    z = block_reduce(z, false);
+    float h = 0.f;
+    for (int v = tid; v < vocab; v += blockDim.x) {
+        const float p = expf(T::to_f(row[v]) / temperature - mx) / z;
+        h += p * logf(p + 1e-5f);
+    }
+    h = -block_reduce(h, false);
+    if (tid == 0) {
+        const float thr = fminf(epsilon, expf(-h) * delta);
+        typ[2 * r] = (1.0f / z > thr) ? 1 : 0;
+        typ[2 * r + 1] = __float_as_int(thr);
+    }
+}
+
+// accept / reject, cache rollback by length (:91-119).  top_k == -1: the typical rule (see kg_typical_kernel);
+// top_k == 1: the greedy rule of :97; top_k > 1:
 // a drafted token survives while rank[i] < top_k (kg_topk_rank_kernel); top_k == 0: while it lies in the
 // pooled top-p nuclei, rank + KG_MAX_ROWS holding kg_topp_member_kernel's table.
 __global__ void kg_accept_kernel(KgLoopBufs b, const float* head_part, int stride, int nblocks, const int* rank, int top_k) {
@@ -382,7 +425,41 @@ __global__ void kg_accept_kernel(KgLoopBufs b, const float* head_part, int strid
         kg_u4* pv = (kg_u4*)b.prev_exit;
         for (int i = threadIdx.x; i < n16; i += blockDim.x) pv[i] = ex[i];
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && top_k == -1) {
+        // typical rule (MTBench :294-314): rank = kg_typical_kernel's table.  start_index moves on by one at every
+        // row that ends a run of matches, whether its posterior test passes or not; no token is written; a failed
+        // test or an eos stops the generation; later rows are compared against the shifted start_index.
+        const int eos = st[KS_EOS], max_infer = st[KS_MAX_INFER];
+        int snew = s, stop = 0, thr_bits = 0, have_thr = 0;
+        for (int i = 0; i < q; ++i) {
+            const int o = s_tok[i];
+            if (i == q - 1 || o == eos || o != b.tokens[snew + 1 + i]) {                  // :295
+                thr_bits = rank[2 * i + 1]; have_thr = 1;                                 // :301
+                snew += 1;                                                                // :307 / :309
+                if (rank[2 * i] == 0) stop = 1;                                           // :310
+                if (o == eos) stop = 1;                                                   // :312
+                if (stop || snew >= max_infer) break;                                     // :313
+            }
+        }
+        if (have_thr) {
+            // the draft loop's confidence threshold is that fp32 value from now on (:301 rebinds the name used at :258)
+            const double d = (double)__int_as_float(thr_bits);
+            const unsigned long long u = __builtin_bit_cast(unsigned long long, d);
+            st[KS_THRESH_LO] = (int)(unsigned)(u & 0xffffffffu);
+            st[KS_THRESH_HI] = (int)(unsigned)(u >> 32);
+        }
+        s_next = b.tokens[snew];
+        const int r = st[KS_ROUND];
+        st[KS_HDR + 2 * r] = snew - s;
+        st[KS_HDR + 2 * r + 1] = q - 1;
+        st[KS_ROUND] = r + 1;
+        st[KS_START] = snew;
+        st[KS_STOP] = stop;
+        st[KS_Q_PREV] = q;
+        if (st[KS_ADAPTER_LEN] > snew) st[KS_ADAPTER_LEN] = snew;
+        kg_round_begin_state(b, st, snew, stop);
+    }
+    if (threadIdx.x == 0 && top_k != -1) {
         const int eos = st[KS_EOS];
         int snew = s, stop = 0;
         for (int i = 0; i < q; ++i) {
@@ -500,6 +577,11 @@ int kg_launch_accept(const KgLoopBufs& b, const float* head_part, int stride, in
 int kg_launch_topp_member(const KgLoopBufs& b, const void* logits, int vocab, float temperature, float top_p, int* member, int dtype, hipStream_t st) {
     if (dtype == KG_F16) hipLaunchKernelGGL(kg_topp_member_kernel<KG_F16>, dim3(KG_MAX_ROWS), dim3(256), 0, st, b, (const unsigned short*)logits, vocab, temperature, top_p, member);
     else hipLaunchKernelGGL(kg_topp_member_kernel<KG_BF16>, dim3(KG_MAX_ROWS), dim3(256), 0, st, b, (const unsigned short*)logits, vocab, temperature, top_p, member);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+int kg_launch_typical(const KgLoopBufs& b, const void* logits, int vocab, float temperature, float epsilon, float delta, int* typ, int dtype, hipStream_t st) {
+    if (dtype == KG_F16) hipLaunchKernelGGL(kg_typical_kernel<KG_F16>, dim3(KG_MAX_ROWS), dim3(256), 0, st, b, (const unsigned short*)logits, vocab, temperature, epsilon, delta, typ);
+    else hipLaunchKernelGGL(kg_typical_kernel<KG_BF16>, dim3(KG_MAX_ROWS), dim3(256), 0, st, b, (const unsigned short*)logits, vocab, temperature, epsilon, delta, typ);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 int kg_launch_topk_rank(const KgLoopBufs& b, const void* logits, int vocab, int* rank, int dtype, hipStream_t st) {

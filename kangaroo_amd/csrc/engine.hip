@@ -51,6 +51,7 @@ struct kg_session {
     char* vlogits; int* topk_rank;     // verify logits rows and rank of each drafted token (top-k verification)
     int accept_top_k;                  // 1: greedy acceptance
     float accept_top_p, temperature;   // accept_top_p > 0: top-p verification on logits / temperature
+    int accept_typical; float typical_epsilon, typical_delta;   // typical verification at `temperature`
     int head_part_stride;
     int prefill_rows;
     // tuning
@@ -189,6 +190,7 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     s->attn_nsplit = 16;
     s->accept_top_k = 1;
     s->accept_top_p = 0.f; s->temperature = 1.f;
+    s->accept_typical = 0; s->typical_epsilon = 0.3f; s->typical_delta = 0.09f;
     s->gemm_prefill = s->v_transposed;           // the GEMM passes need the MFMA attention kernel
     s->bench_layers = s->sh.num_layers;
     s->vanilla_gemv = 0;
@@ -238,6 +240,7 @@ extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
     if (k == "vanilla_gemv") { s->vanilla_gemv = value >= 2 ? 1 : 0; done = true; }   // 1: off, 2: on
     if (k == "bench_layers") { s->bench_layers = value < s->sh.num_layers ? value : s->sh.num_layers; done = true; }
     if (k == "accept_top_k") { if (value > s->sh.vocab_size) return fail(-1, "accept_top_k <= vocab_size"); s->accept_top_k = value; done = true; }
+    if (k == "accept_typical") { s->accept_typical = value >= 2 ? 1 : 0; done = true; }   // 1: off, 2: on
     if (k == "attn_teams") { if (value > 2) return fail(-1, "attn_teams is 1 or 2"); s->attn_teams = value; done = true; }
     if (k == "attn_blocks") { if (value > 32) return fail(-1, "attn_blocks <= 32"); s->attn_blocks = value; done = true; }
     if (k == "persist") { s->persist = (value >= 2 && s->v_transposed && (g_ncu % 8) == 0) ? 1 : 0; done = true; }   // 1: off, 2: on
@@ -266,6 +269,8 @@ extern "C" int kg_session_setf(kg_session* s, const char* key, float value) {
     std::string k(key);
     if (k == "accept_top_p") { if (!(value >= 0.f && value <= 1.f)) return fail(-1, "accept_top_p in [0, 1]"); s->accept_top_p = value; }
     else if (k == "temperature") { if (!(value > 0.f)) return fail(-1, "temperature > 0"); s->temperature = value; }
+    else if (k == "typical_epsilon") s->typical_epsilon = value;
+    else if (k == "typical_delta") s->typical_delta = value;
     else return fail(-1, "unknown key");
     if (s->round_graph) { hipGraphExecDestroy(s->round_graph); s->round_graph = nullptr; s->round_graph_steps = -1; }
     s->prog_n[0] = s->prog_n[1] = s->prog_n[2] = 0;
@@ -277,6 +282,8 @@ extern "C" float kg_session_getf(kg_session* s, const char* key) {
     std::string k(key);
     if (k == "accept_top_p") return s->accept_top_p;
     if (k == "temperature") return s->temperature;
+    if (k == "typical_epsilon") return s->typical_epsilon;
+    if (k == "typical_delta") return s->typical_delta;
     return -1.f;
 }
 
@@ -295,6 +302,7 @@ extern "C" int kg_session_get(kg_session* s, const char* key) {
     if (k == "attn_blocks") return s->attn_blocks;
     if (k == "attn_teams") return s->attn_teams;
     if (k == "accept_top_k") return s->accept_top_k;
+    if (k == "accept_typical") return s->accept_typical;
     if (k == "gemm_prefill") return s->gemm_prefill;
     if (k == "vanilla_gemv") return s->vanilla_gemv;
     if (k == "persist") return s->persist;
@@ -581,7 +589,7 @@ static int build_program(kg_session* s, int which, const KgDyn* dyn, int max_row
         a.norm_w = s->w.final_norm; a.eps = sh.rms_eps;
         a.head_part = s->head_part; a.head_part_stride = s->head_part_stride;
         a.logits_stride = sh.vocab_size;
-        if (which == 0 && (s->accept_top_k > 1 || s->accept_top_p > 0.f)) a.logits_out = s->vlogits;
+        if (which == 0 && (s->accept_top_k > 1 || s->accept_top_p > 0.f || s->accept_typical)) a.logits_out = s->vlogits;
         if (!add_lin(KG_PH_HEAD, OP_HEAD, a)) return 0;
     }
     if (kg_persist_max_blocks(sh.dtype, smem) < nblk) return 0;
@@ -639,11 +647,12 @@ static int enqueue_round(kg_session* s, int steps, hipStream_t st) {
             KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_verify, vrows, cur, s->h2, st));
             cur = s->h2;
         }
-        KG_TRY(run_head(s, s->dyn_verify, vrows, s->h2, 0, s->w.final_norm, (s->accept_top_k > 1 || s->accept_top_p > 0.f) ? s->vlogits : nullptr, &nb, st));
+        KG_TRY(run_head(s, s->dyn_verify, vrows, s->h2, 0, s->w.final_norm, (s->accept_top_k > 1 || s->accept_top_p > 0.f || s->accept_typical) ? s->vlogits : nullptr, &nb, st));
     }
-    if (s->accept_top_p > 0.f) KG_TRY(kg_launch_topp_member(b, s->vlogits, sh.vocab_size, s->temperature, s->accept_top_p, s->topk_rank + KG_MAX_ROWS, sh.dtype, st));
+    if (s->accept_typical) KG_TRY(kg_launch_typical(b, s->vlogits, sh.vocab_size, s->temperature, s->typical_epsilon, s->typical_delta, s->topk_rank, sh.dtype, st));
+    else if (s->accept_top_p > 0.f) KG_TRY(kg_launch_topp_member(b, s->vlogits, sh.vocab_size, s->temperature, s->accept_top_p, s->topk_rank + KG_MAX_ROWS, sh.dtype, st));
     else if (s->accept_top_k > 1) KG_TRY(kg_launch_topk_rank(b, s->vlogits, sh.vocab_size, s->topk_rank, sh.dtype, st));
-    KG_TRY(kg_launch_accept(b, s->head_part, s->head_part_stride, nb, s->topk_rank, s->accept_top_p > 0.f ? 0 : s->accept_top_k, st));
+    KG_TRY(kg_launch_accept(b, s->head_part, s->head_part_stride, nb, s->topk_rank, s->accept_typical ? -1 : (s->accept_top_p > 0.f ? 0 : s->accept_top_k), st));
     return 0;
 }
 
@@ -817,6 +826,11 @@ extern "C" int kg_generate(kg_session* s, int mode, const int32_t* prompt_host, 
     hs[KS_THRESH_HI] = (int)(unsigned)(tb >> 32);
     KG_CHECK_HIP(hipMemcpyAsync(s->state, hs, KS_HDR * sizeof(int), hipMemcpyHostToDevice, st));
     KG_CHECK_HIP(hipMemcpyAsync(s->tokens, prompt_host, (size_t)T0 * sizeof(int), hipMemcpyHostToDevice, st));
+    // the rest of the token buffer starts as eos (:20); only the typical rule ever reads a slot it did not write
+    if (mode == 0 && s->accept_typical) {
+        if (eos_token_id < 0 || eos_token_id >= s->sh.vocab_size) return fail(-1, "the typical rule needs an eos id inside the vocabulary (unwritten token slots hold it)");
+        KG_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(s->tokens + T0), eos_token_id, (size_t)(s->buf.t_max + 64 - T0), st));
+    }
 
     KG_CHECK_HIP(hipMemsetAsync(s->bar + 256, 0, sizeof(unsigned), st));
     KG_CHECK_HIP(hipEventRecord(s->ev_t0, st));
@@ -1128,16 +1142,18 @@ KgLoopBufs ctl_bufs(const CtlScratch& c) {
 extern "C" size_t kg_control_scratch_bytes(void) { return ctl_carve(nullptr, nullptr); }
 
 extern "C" int kg_accept(int dtype, const void* logits, int vocab, int q, const int32_t* drafted_host, int start_index,
-                         int eos_token_id, int rule, int top_k, float top_p, float temperature, int steps, int max_infer,
-                         int adapter_len, int32_t* out_host, void* scratch, void* stream) {
+                         int eos_token_id, int rule, int top_k, float top_p, float temperature, float epsilon, float delta,
+                         int steps, int max_infer, int adapter_len, int32_t* out_host, void* scratch, void* stream) {
     g_err.clear();
     kg_init_once();
     if (!logits || !out_host || !scratch || (q > 1 && !drafted_host)) return fail(-1, "null argument");
     if (dtype != KG_F16 && dtype != KG_BF16) return fail(-1, "dtype");
     if (q < 1 || q > KG_MAX_ROWS - 1 || vocab < 1) return fail(-1, "q must be in [1, 15]");
     if (start_index < 0 || start_index + q + 1 > KG_CTL_TOKENS) return fail(-1, "start_index out of range for the scratch state");
-    if (rule < 0 || rule > 2 || (rule == 1 && (top_k < 2 || top_k > vocab)) || (rule == 2 && (!(top_p > 0.f && top_p <= 1.f) || !(temperature > 0.f))))
-        return fail(-1, "rule: 0 greedy, 1 top-k (2 <= k <= vocab), 2 top-p (0 < p <= 1, temperature > 0)");
+    if (rule < 0 || rule > 3 || (rule == 1 && (top_k < 2 || top_k > vocab)) || (rule == 2 && (!(top_p > 0.f && top_p <= 1.f) || !(temperature > 0.f))) ||
+        (rule == 3 && !(temperature > 0.f)))
+        return fail(-1, "rule: 0 greedy, 1 top-k (2 <= k <= vocab), 2 top-p (0 < p <= 1, temperature > 0), 3 typical (temperature > 0)");
+    if (start_index + 2 * q + 2 > KG_CTL_TOKENS) return fail(-1, "start_index out of range for the scratch state");
     hipStream_t st = (hipStream_t)stream;
     CtlScratch c;
     ctl_carve(&c, scratch);
@@ -1146,13 +1162,18 @@ extern "C" int kg_accept(int dtype, const void* logits, int vocab, int q, const 
     memset(hs, 0, sizeof(hs));
     hs[KS_START] = start_index; hs[KS_END] = start_index + q; hs[KS_ADAPTER_LEN] = adapter_len; hs[KS_ALIVE] = 1;
     hs[KS_MAX_INFER] = max_infer; hs[KS_STEPS] = steps; hs[KS_EOS] = eos_token_id;
+    { const double thr0 = 0.6; unsigned long long tb; memcpy(&tb, &thr0, 8);
+      hs[KS_THRESH_LO] = (int)(unsigned)(tb & 0xffffffffu); hs[KS_THRESH_HI] = (int)(unsigned)(tb >> 32); }
     KG_CHECK_HIP(hipMemcpyAsync(c.state, hs, sizeof(hs), hipMemcpyHostToDevice, st));
+    // token slots the round did not write hold eos, as the loop's buffer does from the start (:20)
+    KG_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(c.tokens + start_index + 1), eos_token_id, (size_t)(2 * q + 1), st));
     if (q > 1) KG_CHECK_HIP(hipMemcpyAsync(c.tokens + start_index + 1, drafted_host, (size_t)(q - 1) * sizeof(int), hipMemcpyHostToDevice, st));
     const int G = (vocab + 15) / 16, nb = G < KG_CTL_RECORDS ? G : KG_CTL_RECORDS;
     KG_TRY(kg_launch_logit_records(logits, vocab, q, nb, c.head_part, c.stride, dtype, st));
-    if (rule == 2) KG_TRY(kg_launch_topp_member(b, logits, vocab, temperature, top_p, c.rank + KG_MAX_ROWS, dtype, st));
+    if (rule == 3) KG_TRY(kg_launch_typical(b, logits, vocab, temperature, epsilon, delta, c.rank, dtype, st));
+    else if (rule == 2) KG_TRY(kg_launch_topp_member(b, logits, vocab, temperature, top_p, c.rank + KG_MAX_ROWS, dtype, st));
     else if (rule == 1) KG_TRY(kg_launch_topk_rank(b, logits, vocab, c.rank, dtype, st));
-    KG_TRY(kg_launch_accept(b, c.head_part, c.stride, nb, c.rank, rule == 2 ? 0 : (rule == 1 ? top_k : 1), st));
+    KG_TRY(kg_launch_accept(b, c.head_part, c.stride, nb, c.rank, rule == 3 ? -1 : (rule == 2 ? 0 : (rule == 1 ? top_k : 1)), st));
     int hs2[KS_HDR + 2];
     KG_CHECK_HIP(hipMemcpyAsync(hs2, c.state, sizeof(hs2), hipMemcpyDeviceToHost, st));
     int tok = 0;
@@ -1167,6 +1188,8 @@ extern "C" int kg_accept(int dtype, const void* logits, int vocab, int q, const 
     out_host[5] = hs2[KS_ALIVE];         // the next round runs (:46, :123)
     out_host[6] = hs2[KS_HDR + 1];       // drafted tokens of the round
     out_host[7] = hs2[KS_ROUND];
+    out_host[8] = hs2[KS_THRESH_LO];     // the draft loop's confidence threshold after the round, as a double (0.6 going in;
+    out_host[9] = hs2[KS_THRESH_HI];     //  only the typical rule changes it, MTBench :301)
     return 0;
 }
 

@@ -97,9 +97,10 @@ struct KgLoopBufs {
 int kg_launch_round_begin(const KgLoopBufs& b, hipStream_t st);
 int kg_launch_step_mid(const KgLoopBufs& b, int step, hipStream_t st);        // after the shallow pass: adapter rows
 int kg_launch_step_end(const KgLoopBufs& b, int step, const float* head_part, int nblocks, hipStream_t st);  // after the draft head
-// rank / top_k: top-k verification (top_k == 1: greedy, rank unused)
+// rank / top_k: top-k verification (top_k == 1: greedy, rank unused; 0: top-p table; -1: typical table)
 int kg_launch_accept(const KgLoopBufs& b, const float* head_part, int stride, int nblocks, const int* rank, int top_k, hipStream_t st);
 int kg_launch_topp_member(const KgLoopBufs& b, const void* logits, int vocab, float temperature, float top_p, int* member, int dtype, hipStream_t st);
+int kg_launch_typical(const KgLoopBufs& b, const void* logits, int vocab, float temperature, float epsilon, float delta, int* typ, int dtype, hipStream_t st);
 int kg_launch_topk_rank(const KgLoopBufs& b, const void* logits, int vocab, int* rank, int dtype, hipStream_t st);
 int kg_launch_vanilla_begin(const KgLoopBufs& b, hipStream_t st);
 int kg_launch_vanilla_end(const KgLoopBufs& b, const float* head_part, int nblocks, hipStream_t st);

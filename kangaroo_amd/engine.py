@@ -231,12 +231,14 @@ class KangarooEngine:
     # ---- fused loops ---------------------------------------------------------------
     def generate(self, prompt_ids, max_new_tokens: int, mode: str = "kangaroo", steps: int = 6, threshold: float = 0.6,
                  eos_token_id: int = 2, max_length: Optional[int] = None, accept_top_k: int = 1,
-                 accept_top_p: Optional[float] = None, temperature: float = 1.0):
+                 accept_top_p: Optional[float] = None, temperature: float = 1.0, accept_typical=None):
         """Whole kangaroo_forward (mode='kangaroo') or plain greedy decoding (mode='vanilla')
         on the device.  accept_top_k > 1: top-k verification (a drafted token is kept while it is
         among the k largest verify logits; evaluation/inference_kangaroo_MTBench.py:377-389) instead
         of the greedy rule.  accept_top_p: top-p verification on softmax(logits / temperature)
         (a drafted token is kept while it lies in the pooled nuclei of the round's rows, :356-374).
+        accept_typical = (epsilon, delta): the "typical" rule at `temperature` (:293-314), reproduced as the
+        reference executes it (start_index moves without a token being written; the draft threshold is rebound).
         Returns (output_ids list, GenStats)."""
         if mode == "kangaroo":
             if self.get_tuning("accept_top_k") != int(accept_top_k):
@@ -246,6 +248,13 @@ class KangarooEngine:
                     (want_p > 0 and self.lib.kg_session_getf(self._handle, b"temperature") != C.c_float(temperature).value):
                 _lib.check(self.lib.kg_session_setf(self._handle, b"temperature", float(temperature)), "kg_session_setf(temperature)")
                 _lib.check(self.lib.kg_session_setf(self._handle, b"accept_top_p", want_p), "kg_session_setf(accept_top_p)")
+            want_t = 2 if accept_typical else 1
+            if self.get_tuning("accept_typical") != want_t - 1 or accept_typical:
+                if accept_typical:
+                    _lib.check(self.lib.kg_session_setf(self._handle, b"temperature", float(temperature)), "kg_session_setf(temperature)")
+                    _lib.check(self.lib.kg_session_setf(self._handle, b"typical_epsilon", float(accept_typical[0])), "kg_session_setf")
+                    _lib.check(self.lib.kg_session_setf(self._handle, b"typical_delta", float(accept_typical[1])), "kg_session_setf")
+                self.set_tuning(accept_typical=want_t)
         if isinstance(prompt_ids, torch.Tensor):
             prompt = prompt_ids.reshape(-1).to("cpu", torch.int32).contiguous()
         else:

@@ -25,11 +25,12 @@ def _ids(inputs) -> torch.Tensor:
     return inputs if isinstance(inputs, torch.Tensor) else inputs.input_ids
 
 
-def _rule_of(do_sample, hyper_k, hyper_p, temperature):
+def _rule_of(do_sample, hyper_k, hyper_p, temperature, epsilon=0.3, delta=0.09):
     """The verification rule as the reference's loops name it: False / "greedy" (inference_kangaroo.py:95-104),
     "top_k" with hyper_k (inference_kangaroo_MTBench.py:377-389) or "top_p" with hyper_p and temperature
-    (:356-374; temperature 0 means greedy there, :282-290).  The rules that draw random numbers
-    ("typical", "typical_sampling") are not offered.  Returns engine.generate keyword arguments."""
+    (:356-374; temperature 0 means greedy there, :282-290), or "typical" with temperature, epsilon and delta
+    (:293-314, reproduced as written there: see KangarooEngine.generate).  "typical_sampling" (:316-354) draws
+    from torch.multinomial and is not offered.  Returns engine.generate keyword arguments."""
     if do_sample in (False, True, None, "greedy"):      # the loop of inference_kangaroo.py is greedy whatever the flag says (:15-129; its caller passes True, :239)
         return {}
     if do_sample == "top_k":
@@ -40,11 +41,14 @@ def _rule_of(do_sample, hyper_k, hyper_p, temperature):
         if not 0.0 < float(hyper_p) <= 1.0:
             raise ValueError("hyper_p must be in (0, 1]")
         return {} if temperature == 0.0 else dict(accept_top_p=float(hyper_p), temperature=float(temperature))
-    raise NotImplementedError(f"verification rule {do_sample!r} is not implemented (greedy, top_k and top_p are)")
+    if do_sample == "typical":
+        return {} if temperature == 0.0 else dict(accept_typical=(float(epsilon), float(delta)), temperature=float(temperature))
+    raise NotImplementedError(f"verification rule {do_sample!r} is not implemented (greedy, top_k, top_p and typical are)")
 
 
 def kangaroo_forward(inputs, model, tokenizer, max_new_tokens, do_sample=False, max_length=2048, EARLY_STOP_LAYER=2,
-                     SPECULATIVE_DECODING_STEPS=6, threshold=0.6, return_stats=False, hyper_k=2, hyper_p=0.8, temperature=0.7):
+                     SPECULATIVE_DECODING_STEPS=6, threshold=0.6, return_stats=False, hyper_k=2, hyper_p=0.8, temperature=0.7,
+                     epsilon=0.3, delta=0.09):
     ids = _ids(inputs)
     if ids.shape[0] != 1:
         raise ValueError("batch size 1 only")
@@ -52,7 +56,7 @@ def kangaroo_forward(inputs, model, tokenizer, max_new_tokens, do_sample=False, 
         raise ValueError("EARLY_STOP_LAYER differs from the model's layer split")
     out, st = model.engine.generate(ids[0], max_new_tokens, mode="kangaroo", steps=SPECULATIVE_DECODING_STEPS,
                                     threshold=threshold, eos_token_id=_eos(tokenizer), max_length=max_length,
-                                    **_rule_of(do_sample, hyper_k, hyper_p, temperature))
+                                    **_rule_of(do_sample, hyper_k, hyper_p, temperature, epsilon, delta))
     accept_length_list = [1] + st.accept_lengths
     res = ([out], st.new_tokens, len(accept_length_list) - 1, accept_length_list)
     return res + (st,) if return_stats else res

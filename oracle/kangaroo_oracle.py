@@ -291,6 +291,39 @@ class Trace:
     prefill_last_logits: Optional[torch.Tensor] = None
 
 
+def typical_block(logits, global_tokens, start_index, end_index, eos_token_id, temperature, epsilon, delta, max_infer_steps):
+    """The "typical" branch of evaluation/inference_kangaroo_MTBench.py:293-314, as written there: at every row
+    whose argmax ends the run of matches (last row, eos, or a token other than the drafted one) the row's
+    posterior is tested against min(epsilon, exp(-entropy) * delta); start_index moves on by ONE either way
+    (:307,309), no token is written, a failed test or an eos stops the whole generation (:310,312), and the loop
+    carries on with the next row against the SHIFTED start_index unless it stopped or ran out of budget (:313).
+    The branch also rebinds the name `threshold` (:301), which is the draft loop's confidence threshold of :258
+    from then on; the last value is returned for the caller to do the same.
+    Returns (new start_index, stop, threshold tensor or None)."""
+    output_tokens = torch.argmax(logits, dim=-1)                                                  # :276
+    output_length = end_index - start_index                                                       # :277
+    stop = False
+    threshold = None
+    for i in range(output_length):                                                                # :294
+        if i == output_length - 1 or output_tokens[0, i] == eos_token_id or \
+                output_tokens[0, i] != global_tokens[0, start_index + 1 + i]:                     # :295
+            posterior_prob = torch.softmax(logits[:, i, :] / temperature, dim=-1)                 # :297
+            posterior_entropy = -torch.sum(posterior_prob * torch.log(posterior_prob + 1e-5), dim=-1)   # :298-300
+            threshold = torch.minimum(torch.ones_like(posterior_entropy) * epsilon,
+                                      torch.exp(-posterior_entropy) * delta)                      # :301-304
+            is_accepted = posterior_prob.max(dim=-1).values > threshold                           # :305
+            if is_accepted:
+                start_index += 1                                                                  # :307
+            else:
+                start_index += 1                                                                  # :309
+                stop = True
+            if output_tokens[0, i] == eos_token_id:                                               # :311
+                stop = True
+            if stop or start_index >= max_infer_steps:                                            # :313
+                break
+    return start_index, stop, threshold
+
+
 def accept_block(logits, global_tokens, start_index, end_index, eos_token_id, accept_top_k=1, accept_top_p=None, temperature=1.0):
     """The verification block of one round, evaluation/inference_kangaroo.py:92-102 (greedy) with the
     membership tests of evaluation/inference_kangaroo_MTBench.py:356-389 swapped in for :97 when asked.
@@ -328,7 +361,8 @@ def accept_block(logits, global_tokens, start_index, end_index, eos_token_id, ac
 def kangaroo_forward(input_ids: torch.Tensor, model, eos_token_id: int, max_new_tokens: int,
                      max_length: int = 2048, EARLY_STOP_LAYER: int = 2, SPECULATIVE_DECODING_STEPS: int = 6,
                      threshold: float = 0.6, trace: Optional[Trace] = None, keep_logits: bool = False,
-                     accept_top_k: int = 1, accept_top_p: Optional[float] = None, temperature: float = 1.0):
+                     accept_top_k: int = 1, accept_top_p: Optional[float] = None, temperature: float = 1.0,
+                     accept_typical: Optional[Tuple[float, float]] = None):
     """evaluation/inference_kangaroo.py:15-129, statement for statement, with KV
     truncation expressed on the [1,Hkv,T,hd] tensors exactly as :108-119 does.
 
@@ -341,6 +375,10 @@ def kangaroo_forward(input_ids: torch.Tensor, model, eos_token_id: int, max_new_
     every verify row's nucleus (tokens, by falling softmax(logits / temperature), whose predecessors
     sum to <= accept_top_p; the first always) is pooled over the round's rows (:365 flattens them),
     and a drafted token is kept while it is in the pool.
+
+    accept_typical = (epsilon, delta) swaps it for the "typical" branch of
+    evaluation/inference_kangaroo_MTBench.py:293-314 at `temperature` (see typical_block: no token is written,
+    and the draft loop's threshold is replaced by the branch's last posterior threshold).
 
     Returns ([output_ids], new_token, idx, accept_length_list)."""
     context_tokens = input_ids
@@ -414,8 +452,14 @@ def kangaroo_forward(input_ids: torch.Tensor, model, eos_token_id: int, max_new_
             if keep_logits:
                 trace.verify_logits.append(logits[0].clone())
 
-        start_index, stop_now = accept_block(logits, global_tokens, start_index, end_index, eos_token_id,   # :95-102
-                                             accept_top_k, accept_top_p, temperature)
+        if accept_typical is not None:
+            start_index, stop_now, new_threshold = typical_block(logits, global_tokens, start_index, end_index, eos_token_id,
+                                                                 temperature, accept_typical[0], accept_typical[1], max_infer_steps)
+            if new_threshold is not None:
+                threshold = new_threshold                                                         # MTBench :301 rebinds the name
+        else:
+            start_index, stop_now = accept_block(logits, global_tokens, start_index, end_index, eos_token_id,   # :95-102
+                                                 accept_top_k, accept_top_p, temperature)
         stop = stop or stop_now
         accept_length_list.append(start_index - start_index_copy)                                 # :104
 

@@ -4,7 +4,8 @@ kg_accept (accept / reject, rollback lengths, loop bound) against the oracle's a
 evaluation/inference_kangaroo_MTBench.py:356-389), and kg_draft_step (adapter rows, drafted token,
 confidence, second early exit) against the statements of evaluation/inference_kangaroo.py:55-61,74,79-83.
 Integer results: bit-exact.  The logits handed to the device are the stored 16-bit rows, and the oracle sees
-exactly those values, so no tolerance is involved anywhere except the fp32 confidence (1e-5)."""
+exactly those values, so no tolerance is involved anywhere except the fp32 confidence (1e-5) and the typical
+rule's fp32 posterior threshold (2e-4)."""
 import ctypes as C
 import struct
 
@@ -30,15 +31,16 @@ def _scratch(lib):
     return torch.zeros(lib.kg_control_scratch_bytes(), dtype=torch.uint8, device=DEV)
 
 
-def run_accept(lib, logits, drafted, s, eos, rule=0, top_k=1, top_p=0.0, temperature=1.0, steps=6, max_infer=2048, adapter_len=None, code=_lib.DT_F16):
+def run_accept(lib, logits, drafted, s, eos, rule=0, top_k=1, top_p=0.0, temperature=1.0, steps=6, max_infer=2048, adapter_len=None, code=_lib.DT_F16,
+               epsilon=0.3, delta=0.09):
     q = logits.shape[0]
     lg = logits.to(DEV).contiguous()
     dr = (C.c_int32 * max(1, q - 1))(*drafted)
-    out = (C.c_int32 * 8)()
+    out = (C.c_int32 * 10)()
     scr = _scratch(lib)
     alen = s + q - 1 if adapter_len is None else adapter_len
     _lib.check(lib.kg_accept(code, C.c_void_p(lg.data_ptr()), logits.shape[1], q, C.cast(dr, I32P), s, eos, rule, top_k, top_p, temperature,
-                             steps, max_infer, alen, C.cast(out, I32P), C.c_void_p(scr.data_ptr()), _stream()), "kg_accept")
+                             epsilon, delta, steps, max_infer, alen, C.cast(out, I32P), C.c_void_p(scr.data_ptr()), _stream()), "kg_accept")
     return list(out)
 
 
@@ -204,6 +206,37 @@ def test_top_p_equal_probabilities():
             assert (got[0] == 2) == (t in members), (p, t)
 
 
+@pytest.mark.parametrize("temp,eps,delta", [(0.7, 0.3, 0.09), (1.0, 0.9, 1.5), (1.0, 0.02, 5.0), (1.3, 0.9, 40.0)])
+def test_typical_rule_as_the_reference_executes_it(temp, eps, delta):
+    """evaluation/inference_kangaroo_MTBench.py:293-314 through the oracle's typical_block: start_index moves by
+    one per row that ends a run of matches, nothing is written, a failed posterior test or an eos stops, later
+    rows are compared against the shifted start_index, and the draft threshold is rebound to the last
+    min(epsilon, exp(-entropy) * delta)."""
+    lib = _lib.lib()
+    eos = 2
+    for q, seed, scale in ((1, 1, 1.0), (4, 2, 1.0), (7, 3, 0.5), (7, 4, 0.25), (5, 5, 0.1)):
+        lg = distinct_rows(q, 300 + seed, scale)
+        am = lg.float().argmax(-1).tolist()
+        sets = [am[:q - 1]]
+        for i in range(q - 1):
+            d = list(am[:q - 1]); d[i] = (d[i] + 3) % V
+            sets.append(d)
+        if q > 2:
+            sets.append([am[1]] + am[1:q - 1])                  # after a shift, row 1's argmax is compared with ITS OWN slot's neighbour
+        for drafted in sets:
+            for max_infer in (2048, 31):
+                s = 25
+                got = run_accept(lib, lg, drafted, s, eos, rule=3, temperature=temp, epsilon=eps, delta=delta, max_infer=max_infer)
+                toks = torch.full((1, s + 2 * q + 3), eos, dtype=torch.long)
+                toks[0, s + 1:s + q] = torch.tensor(drafted, dtype=torch.long)
+                snew, stop, thr = ko.typical_block(lg.float().unsqueeze(0), toks, s, s + q, eos, temp, eps, delta, max_infer)
+                assert (got[0], got[1], got[2], got[3]) == (snew - s, int(toks[0, snew]), int(stop), snew), (q, drafted, got)
+                dev_thr = struct.unpack("d", struct.pack("ii", got[8], got[9]))[0]
+                # exp(-entropy): the entropy is an fp32 sum of 32000 terms, added in another order on the device
+                assert thr is not None and abs(dev_thr - float(thr)) <= 2e-4 * float(thr), (dev_thr, float(thr))
+                assert got[5] == int((not stop) and snew < max_infer - 1 - 6)
+
+
 @pytest.mark.parametrize("dtype,code", [(torch.float16, _lib.DT_F16), (torch.bfloat16, _lib.DT_BF16)], ids=["f16", "bf16"])
 def test_draft_step_control(dtype, code):
     lib = _lib.lib()
@@ -244,12 +277,12 @@ def test_control_entry_points_refuse_bad_arguments():
     lib = _lib.lib()
     scr = _scratch(lib)
     lg = rows(2, 1).to(DEV)
-    out = (C.c_int32 * 8)()
+    out = (C.c_int32 * 10)()
     dr = (C.c_int32 * 1)(3)
     def call(q=2, s=5, rule=0, k=1, p=0.0, t=1.0):
-        return lib.kg_accept(0, C.c_void_p(lg.data_ptr()), V, q, C.cast(dr, I32P), s, -1, rule, k, p, t, 6, 2048, 5, C.cast(out, I32P), C.c_void_p(scr.data_ptr()), _stream())
+        return lib.kg_accept(0, C.c_void_p(lg.data_ptr()), V, q, C.cast(dr, I32P), s, -1, rule, k, p, t, 0.3, 0.09, 6, 2048, 5, C.cast(out, I32P), C.c_void_p(scr.data_ptr()), _stream())
     assert call() == 0
     assert call(q=16) == -1 and call(q=0) == -1 and call(s=-1) == -1 and call(s=5000) == -1
-    assert call(rule=3) == -1 and call(rule=1, k=1) == -1 and call(rule=2, p=0.0) == -1 and call(rule=2, p=0.5, t=0.0) == -1
+    assert call(rule=4) == -1 and call(rule=3, t=0.0) == -1 and call(rule=1, k=1) == -1 and call(rule=2, p=0.0) == -1 and call(rule=2, p=0.5, t=0.0) == -1
     assert lib.kg_draft_step(0, C.c_void_p(lg.data_ptr()), V, 6, 6, 0.6, 5, 6, 5, C.cast(out, I32P), C.c_void_p(scr.data_ptr()), _stream()) == -1
     assert lib.kg_draft_step(0, C.c_void_p(lg.data_ptr()), V, 0, 6, 0.6, 0, 1, 0, C.cast(out, I32P), C.c_void_p(scr.data_ptr()), _stream()) == -1

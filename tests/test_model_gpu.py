@@ -191,6 +191,8 @@ def test_fused_loop_matches_reference_golden(path):
     rule = dict(do_sample="top_k", hyper_k=top_k) if top_k > 1 else {}
     if meta.get("accept_top_p"):                 # top-p verification (:356-374)
         rule = dict(do_sample="top_p", hyper_p=meta["accept_top_p"], temperature=meta["temperature"])
+    if meta.get("accept_typical"):               # typical verification (:293-314)
+        rule = dict(do_sample="typical", temperature=meta["temperature"], epsilon=meta["accept_typical"][0], delta=meta["accept_typical"][1])
     for pi in range(meta["n_prompts"]):
         ids = torch.from_numpy(z[f"p{pi}/input_ids"]).cuda()
         out, new_tok, idx, accept, st = kangaroo_forward(ids, model, meta["eos"], meta["max_new_tokens"], EARLY_STOP_LAYER=meta["exit_layer"],

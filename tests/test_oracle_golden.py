@@ -47,7 +47,7 @@ def test_loop_matches_reference(path):
             ids, model, meta["eos"], meta["max_new_tokens"], EARLY_STOP_LAYER=meta["exit_layer"],
             SPECULATIVE_DECODING_STEPS=meta["steps"], threshold=meta["threshold"], trace=tr, keep_logits=True,
             accept_top_k=meta.get("accept_top_k", 1), accept_top_p=meta.get("accept_top_p"),
-            temperature=meta.get("temperature") or 1.0)
+            temperature=meta.get("temperature") or 1.0, accept_typical=meta.get("accept_typical"))
         assert out[0] == z[f"p{pi}/output_ids"].tolist()
         assert new_token == int(z[f"p{pi}/new_token"])
         assert idx == int(z[f"p{pi}/idx"])
