@@ -99,6 +99,91 @@ def cpu_baseline(shape, L, base_sd_gpu, adapter_sd_gpu, steps, thr, model, n_pro
             "all_differences_within_tol": all(d["kind"] == "none" or d["within_tol"] for d in diffs)}
 
 
+def main_tp(a, shape, L, ds, hs, tdt, dev, dist, rank, world):
+    """--tp N: every group of N ranks holds ONE model whose remaining layers are split N ways (kangaroo_amd/tp.py);
+    the draft stack is replicated.  The loop is driven pass by pass (the partial sums of every layer cross the
+    process group between kernel launches), so this path is launch-bound: it exists to run the >= 33B-class
+    configuration across GPUs with exact rank-order sums, not to set a speed record.  Groups decode disjoint
+    prompts; the job's tokens are counted once per group."""
+    from kangaroo_amd.inference import kangaroo_forward_stepwise
+    from kangaroo_amd.tp import DistGroup, LocalGroup, TPKangarooModel
+    if a.tp_local:
+        group, n_groups, gidx = LocalGroup(a.tp), world, rank
+    else:
+        if dist is None or world % a.tp:
+            sys.exit(f"bench.py --tp {a.tp}: launch a multiple of {a.tp} ranks (WORLD_SIZE is {world}), or rehearse on one GPU with --tp-local")
+        n_groups, gidx = world // a.tp, rank // a.tp
+        pgs = [dist.new_group(list(range(g * a.tp, (g + 1) * a.tp))) for g in range(n_groups)]
+        group = DistGroup(pgs[gidx])
+    base_sd, adapter_sd = synth_state_dicts(shape, L, seed=0, dtype=tdt, recipe=Recipe.agreeable(ds, hs), device=dev)
+    model = TPKangarooModel(shape, base_sd, adapter_sd, tdt, L, group, device=dev)
+    del base_sd, adapter_sd
+    torch.cuda.empty_cache()
+    K, W = a.steps, a.warmup
+    allp = [p for p in spec_bench_prompts(shape.vocab_size, 4 * (K + W) * n_groups) if p.input_ids.shape[1] <= 256][:(K + W) * n_groups]
+    mine = allp[gidx * (K + W):(gidx + 1) * (K + W)]
+    warm, timed = mine[:W], mine[W:]
+    new = min(a.max_new_tokens, 128)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(p, steps):
+        model.head_model.single_rows_in_verify_arithmetic = (steps == 0)      # the comparator's lone rows in a verify row's arithmetic
+        return kangaroo_forward_stepwise(p.input_ids.to(dev), model, -1, new, EARLY_STOP_LAYER=L, SPECULATIVE_DECODING_STEPS=steps, threshold=a.threshold)
+
+    for p in warm:
+        run(p, a.spec_steps)
+    barrier()
+    t0 = time.time()
+    outs = [run(p, a.spec_steps) for p in timed]
+    barrier()
+    elapsed = time.time() - t0
+    new_tokens = sum(o[1] for o in outs)
+    # plain greedy decoding over the same kernels: the same loop with no draft steps (one shallow pass + one verify row per token)
+    torch.cuda.synchronize()
+    tv0 = time.time()
+    van = [run(p, 0) for p in timed]
+    torch.cuda.synchronize()
+    tv = time.time() - tv0
+    agree = sum(int(v[0][0][:min(len(v[0][0]), len(o[0][0]))] == o[0][0][:min(len(v[0][0]), len(o[0][0]))]) for v, o in zip(van, outs))
+    leader = a.tp_local or (rank % a.tp == 0)
+    tot = torch.tensor([float(new_tokens) if leader else 0.0, elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = tot.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        total_tokens, t_job = float(tot[0]), float(tmax[1])
+    else:
+        total_tokens, t_job = float(tot[0]), elapsed
+    acc = [x for o in outs for x in o[3]]
+    eng = model.engine
+    us, wbytes = eng.bench_op("gateup", 1, iters=32)
+    ach = wbytes / (us * 1e-6) / 1e9
+    res = {"metric": "decode tokens/s at bsz=1 (Kangaroo, prefill included)", "value": total_tokens / t_job, "unit": "tokens/s",
+           "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * t_job / max(1, K), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+           "config": {"workload": f"{a.model} shape {'fp16' if a.dtype == 'f16' else 'bf16'} Kangaroo exitlayer={L} steps={a.spec_steps} thr={a.threshold} greedy, "
+                                  f"synthetic prompts <= 256 tokens, max_new_tokens={new}, remaining layers tensor-parallel x{a.tp} "
+                                  f"({'all ranks rehearsed on one GPU' if a.tp_local else 'RCCL all_gather + rank-order sum'}), pass-by-pass loop",
+                      "prompts_per_group": K, "parallelism": f"tp{a.tp} x {n_groups} group(s)"},
+           "mean_accept": sum(acc) / max(1, len(acc)),
+           "vanilla_tokens_per_s_rank0": sum(v[1] for v in van) / tv, "speedup_vs_vanilla": (new_tokens / elapsed) / (sum(v[1] for v in van) / tv),
+           "lossless": f"{agree}/{len(timed)} prompts token-identical to plain greedy decoding over the same tensor-parallel kernels",
+           "roofline": {"bound": "hbm", "kernel": "kg_linear_kernel<GEMV, RMSNorm, SiLU*mul> (gate/up projection of a replicated draft layer; the loop itself is launch-bound)",
+                        "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "us_per_launch": us, "algorithmic_bytes_per_launch": wbytes},
+           "cpu_baseline": None}
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +195,9 @@ def main():
     ap.add_argument("--threshold", type=float, default=0.6)
     ap.add_argument("--recipe", default=f"{CAL_RECIPE[0]}:{CAL_RECIPE[1]}")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="storage / MFMA input type of weights, activations and caches")
+    ap.add_argument("--tp", type=int, default=1, help="tensor-parallel degree of the remaining-layer verify pass (the >= 33B-class configuration): "
+                    "ranks form groups of this many GPUs, one replica per group")
+    ap.add_argument("--tp-local", action="store_true", help="rehearse all --tp ranks of a group on ONE GPU, shard after shard (no process group)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-prompts", type=int, default=4, help="prompts of the bounded CPU-baseline sample (32 tokens in, 32 out each)")
     ap.add_argument("--no-vanilla", action="store_true")
@@ -140,6 +228,8 @@ def main():
     L = DEFAULT_EXIT_LAYER.get(a.model, 2)
     ds, hs = [float(x) for x in a.recipe.split(":")]
     tdt = torch.float16 if a.dtype == "f16" else torch.bfloat16
+    if a.tp > 1:
+        return main_tp(a, shape, L, ds, hs, tdt, dev, dist, rank, world)
     base_sd, adapter_sd = synth_state_dicts(shape, L, seed=0, dtype=tdt, recipe=Recipe.agreeable(ds, hs), device=dev)
     model = KangarooModel.from_state_dicts(shape, base_sd, adapter_sd, tdt, L, device=dev)
     eng = model.engine

@@ -40,7 +40,8 @@ typedef struct {
     int intermediate_size, vocab_size;
     float rms_eps;
     int max_positions;         /* rows of the RoPE tables */
-    int exit_layer;            /* EARLY_STOP_LAYER: layers [0, exit) draft, [exit, N) verify */
+    int exit_layer;            /* EARLY_STOP_LAYER: layers [0, exit) draft, [exit, N) verify; == num_layers: a draft-only
+                                  session (pass-by-pass entry points only) whose remaining layers run elsewhere */
 } kg_shape;
 
 typedef struct {
@@ -93,7 +94,11 @@ const char* kg_last_error(void);
  * (kangaroo/adapter.py:170-172,222,242; kangaroo/kangaroo_model.py:34).
  *   prologue 0: x used as is; 1: x = RMSNorm(x; norm_w, eps) (adapter.py:254-259)
  *   epilogue 0: out = y; 1: out = resid + y (adapter.py:304); 3: out = silu(y_gate) * y_up
- *            (adapter.py:242, rows interleaved as wgu)
+ *            (adapter.py:242, rows interleaved as wgu); 5: out = y as unrounded fp32 (out is float*,
+ *            out_stride in floats; <= 16 rows, no prologue): the partial sums of a row-split projection
+ *            of a tensor-parallel layer, which the caller adds up across ranks
+ * n_rows == -1 is ONE row computed by the MFMA kernel of a multi-row pass (bit-identical to that row
+ * inside a verify pass; kg_qkv_rope_append takes it too).
  * n_rows == 1 runs the wave-reduced GEMV, 2..16 the MFMA decode kernel, 17..128 the prefill GEMM
  * kernel (the base model's prompt pass, evaluation/inference_kangaroo.py:30; nblocks / nwaves unused;
  * with prologue 1 the rows are normalised into the scratch buffer first, once per pass).
@@ -228,7 +233,8 @@ int kg_forward_layers(kg_session* s, int layer_begin, int layer_end, const void*
 int kg_final_norm(kg_session* s, const void* x, int n_rows, void* out, void* stream);
 /* AdapterModel.forward_early_stop (kangaroo/adapter.py:378-460) on n_rows rows at pos0.. */
 int kg_adapter_forward(kg_session* s, const void* x_in, int pos0, int n_rows, void* h_out, void* stream);
-/* head_model (kangaroo/kangaroo_model.py:34-44) on already-normalised rows */
+/* head_model (kangaroo/kangaroo_model.py:34-44) on already-normalised rows; n_rows == -1: one row in a
+ * multi-row pass's arithmetic, as for kg_linear */
 int kg_head_logits(kg_session* s, const void* x, int n_rows, void* logits_out, int* argmax_out, float* pmax_out, void* stream);
 
 /* The whole kangaroo_forward (evaluation/inference_kangaroo.py:15-129): prefill, then

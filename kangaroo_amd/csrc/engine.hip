@@ -163,7 +163,9 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     if (shape->hidden_size % 32 || shape->intermediate_size % 32) return fail(-1, "hidden_size and intermediate_size must be multiples of 32");
     if (shape->head_dim != 16 && shape->head_dim != 32 && shape->head_dim != 64 && shape->head_dim != 128) return fail(-1, "head_dim must be 16, 32, 64 or 128");
     if (shape->num_heads % shape->num_kv_heads) return fail(-1, "num_heads must be a multiple of num_kv_heads");
-    if (shape->exit_layer < 1 || shape->exit_layer >= shape->num_layers) return fail(-1, "exit_layer must be in [1, num_layers)");
+    // exit_layer == num_layers: a draft-only session (shallow layers, adapter, head) whose remaining layers run elsewhere
+    // (tensor-parallel shards); kg_generate refuses it
+    if (shape->exit_layer < 1 || shape->exit_layer > shape->num_layers) return fail(-1, "exit_layer must be in [1, num_layers]");
     if (buffers->t_max > shape->max_positions) return fail(-1, "t_max exceeds the RoPE table");
     if (buffers->workspace_bytes < kg_workspace_bytes(shape, buffers->t_max)) return fail(-1, "workspace too small");
     kg_init_once();
@@ -500,10 +502,12 @@ extern "C" int kg_adapter_forward(kg_session* s, const void* x_in, int pos0, int
 extern "C" int kg_head_logits(kg_session* s, const void* x, int n_rows, void* logits_out, int* argmax_out, float* pmax_out, void* stream) {
     g_err.clear();
     hipStream_t st = (hipStream_t)stream;
+    const int min_rows = (n_rows == -1) ? 2 : 1;          // -1: one row in a multi-row pass's arithmetic (see kg_linear)
+    if (n_rows == -1) n_rows = 1;
     if (!s || !x || n_rows < 1 || n_rows > KG_MAX_ROWS) return fail(-1, "bad argument");
     KG_TRY(kg_launch_set_dyn(s->dyn_call, 1, n_rows, 0, st));
     int nb = 0;
-    KG_TRY(run_head(s, s->dyn_call, n_rows == 1 ? 1 : n_rows, x, 0, nullptr, logits_out, &nb, st));
+    KG_TRY(run_head(s, s->dyn_call, n_rows < min_rows ? min_rows : n_rows, x, 0, nullptr, logits_out, &nb, st));
     if (argmax_out || pmax_out) {
         KG_TRY(kg_launch_head_finalize(s->dyn_call, s->head_part, s->head_part_stride, nb, n_rows,
                                        argmax_out ? argmax_out : s->head_tok, pmax_out ? pmax_out : s->head_pmax, st));
@@ -792,6 +796,7 @@ extern "C" int kg_generate(kg_session* s, int mode, const int32_t* prompt_host, 
     g_err.clear();
     if (!s || !prompt_host || !out_tokens_host || !result) return fail(-1, "null argument");
     if (mode != 0 && mode != 1) return fail(-1, "mode must be 0 (kangaroo) or 1 (vanilla)");
+    if (s->sh.exit_layer >= s->sh.num_layers) return fail(-1, "this session holds no remaining layers (draft-only): drive it pass by pass");
     if (context_length < 1 || max_length > s->buf.t_max || context_length >= max_length) return fail(-1, "context_length / max_length out of range");
     if (mode == 0 && (steps < 0 || steps + 1 > KG_MAX_ROWS - 1)) return fail(-1, "steps out of range");
     if (max_new_tokens < 1) return fail(-1, "max_new_tokens must be >= 1");
@@ -993,8 +998,13 @@ extern "C" int kg_linear(int dtype, const void* w_packed, int N, int K, const vo
     g_err.clear();
     kg_init_once();
     if (!w_packed || !x || !out || !scratch) return fail(-1, "null argument");
-    if (n_rows < 1 || n_rows > KG_GEMM_ROWS) return fail(-1, "n_rows must be in [1, 128]");
-    if (epilogue != EPI_STORE && epilogue != EPI_RESID && epilogue != EPI_SILU_MUL) return fail(-1, "epilogue must be 0, 1 or 3");
+    // n_rows == -1: ONE row in the arithmetic of a multi-row pass (the MFMA kernel with one valid row), so that a row
+    // computed alone and the same row inside a verify pass agree bit for bit
+    const int min_rows = (n_rows == -1) ? 2 : 1;
+    if (n_rows == -1) n_rows = 1;
+    if (n_rows < 1 || n_rows > KG_GEMM_ROWS) return fail(-1, "n_rows must be in [1, 128] (or -1)");
+    if (epilogue != EPI_STORE && epilogue != EPI_RESID && epilogue != EPI_SILU_MUL && epilogue != EPI_STORE_F32) return fail(-1, "epilogue must be 0, 1, 3 or 5");
+    if (epilogue == EPI_STORE_F32 && (n_rows > KG_MAX_ROWS || prologue != PRO_NONE)) return fail(-1, "epilogue 5 (fp32 partial sums) takes at most 16 rows and no prologue");
     if (prologue == PRO_RMSNORM && !norm_w) return fail(-1, "norm_w required");
     if (epilogue == EPI_RESID && !resid) return fail(-1, "resid required");
     hipStream_t st = (hipStream_t)stream;
@@ -1009,7 +1019,7 @@ extern "C" int kg_linear(int dtype, const void* w_packed, int N, int K, const vo
         a.x = xn; prologue = PRO_NONE;
     }
     int rc = (n_rows > KG_MAX_ROWS) ? kg_launch_gemm(a, dtype, prologue, epilogue, st)       // prefill-sized pass
-                                    : kg_launch_linear(a, dtype, n_rows, prologue, epilogue, nblocks > 0 ? nblocks : g_ncu * 2, nwaves > 0 ? nwaves : 8, st);
+                                    : kg_launch_linear(a, dtype, n_rows < min_rows ? min_rows : n_rows, prologue, epilogue, nblocks > 0 ? nblocks : g_ncu * 2, nwaves > 0 ? nwaves : 8, st);
     if (rc == -3) return fail(-3, "rows x K exceed LDS");
     if (rc) return fail(rc, "kg_launch_linear failed");
     return 0;
@@ -1027,6 +1037,8 @@ extern "C" int kg_qkv_rope_append(int dtype, const void* wqkv_packed, int d, int
     g_err.clear();
     kg_init_once();
     if (!wqkv_packed || !x || !norm_w || !rope_cos || !rope_sin || !q_out || !k_cache || !v_cache || !scratch) return fail(-1, "null argument");
+    const int min_rows = (n_rows == -1) ? 2 : 1;          // -1: one row in a multi-row pass's arithmetic (see kg_linear)
+    if (n_rows == -1) n_rows = 1;
     if (n_rows < 1 || n_rows > KG_GEMM_ROWS || pos0 < 0 || pos0 + n_rows > t_max) return fail(-1, "bad rows / positions");
     hipStream_t st = (hipStream_t)stream;
     KgDyn* dyn = (KgDyn*)scratch;
@@ -1041,7 +1053,7 @@ extern "C" int kg_qkv_rope_append(int dtype, const void* wqkv_packed, int d, int
         a.x = xn;
     }
     int rc = (n_rows > KG_MAX_ROWS) ? kg_launch_gemm(a, dtype, PRO_NONE, EPI_ROPE_KV, st)
-                                    : kg_launch_linear(a, dtype, n_rows, PRO_RMSNORM, EPI_ROPE_KV, nblocks > 0 ? nblocks : g_ncu * 2, nwaves > 0 ? nwaves : 8, st);
+                                    : kg_launch_linear(a, dtype, n_rows < min_rows ? min_rows : n_rows, PRO_RMSNORM, EPI_ROPE_KV, nblocks > 0 ? nblocks : g_ncu * 2, nwaves > 0 ? nwaves : 8, st);
     if (rc) return fail(rc, "kg_launch_linear failed");
     return 0;
 }

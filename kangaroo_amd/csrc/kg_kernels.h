@@ -3,7 +3,7 @@
 #include "kg_common.h"
 
 enum { PRO_NONE = 0, PRO_RMSNORM = 1 };
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_ROPE_KV = 2, EPI_SILU_MUL = 3, EPI_HEAD = 4 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_ROPE_KV = 2, EPI_SILU_MUL = 3, EPI_HEAD = 4, EPI_STORE_F32 = 5 };
 
 struct KgLinArgs {
     const void* W;              // packed weights, ceil16(N) x K

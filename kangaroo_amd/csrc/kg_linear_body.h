@@ -96,6 +96,11 @@ __device__ __forceinline__ void epilogue_pair(const KgLinArgs& a, int n0, int m,
     if (EPI == EPI_STORE) {
         if (n0 < a.N) st16<COH>(&out[(size_t)m * a.out_stride + n0], T::from_f(v0));
         if (n0 + 1 < a.N) st16<COH>(&out[(size_t)m * a.out_stride + n0 + 1], T::from_f(v1));
+    } else if (EPI == EPI_STORE_F32) {
+        // unrounded fp32 sums: the partial products of a tensor-parallel shard, added up across ranks by the caller
+        float* o32 = (float*)a.out;
+        if (n0 < a.N) o32[(size_t)m * a.out_stride + n0] = v0;
+        if (n0 + 1 < a.N) o32[(size_t)m * a.out_stride + n0 + 1] = v1;
     } else if (EPI == EPI_RESID) {
         // residual rows of this block were staged in LDS by the prologue: [it][m][16]
         const unsigned short* res = (const unsigned short*)side + ((size_t)it * M + m) * 16 + (n0 & 15);

@@ -16,6 +16,9 @@ static int launch_epi(const KgLinArgs& a, int epi, dim3 grid, dim3 block, size_t
     case EPI_ROPE_KV: hipLaunchKernelGGL((kg_linear_kernel<DT, MODE, PRO, EPI_ROPE_KV>), grid, block, smem, st, a); break;
     case EPI_SILU_MUL: hipLaunchKernelGGL((kg_linear_kernel<DT, MODE, PRO, EPI_SILU_MUL>), grid, block, smem, st, a); break;
     case EPI_HEAD: hipLaunchKernelGGL((kg_linear_kernel<DT, MODE, PRO, EPI_HEAD>), grid, block, smem, st, a); break;
+    case EPI_STORE_F32:
+        if (PRO != PRO_NONE) return -1;          // only the row-split projections of a tensor-parallel layer produce partial sums
+        hipLaunchKernelGGL((kg_linear_kernel<DT, MODE, PRO_NONE, EPI_STORE_F32>), grid, block, smem, st, a); break;
     default: return -1;
     }
     return 0;
@@ -85,6 +88,7 @@ template <int DT, int MODE, int PRO, int EPI> static void set_attr() {
 template <int DT, int MODE, int PRO> static void set_attr_epi() {
     set_attr<DT, MODE, PRO, EPI_STORE>(); set_attr<DT, MODE, PRO, EPI_RESID>(); set_attr<DT, MODE, PRO, EPI_ROPE_KV>();
     set_attr<DT, MODE, PRO, EPI_SILU_MUL>(); set_attr<DT, MODE, PRO, EPI_HEAD>();
+    if (PRO == PRO_NONE) set_attr<DT, MODE, PRO_NONE, EPI_STORE_F32>();
 }
 void kg_linear_init() {
     set_attr_epi<KG_F16, MODE_MFMA, PRO_NONE>(); set_attr_epi<KG_F16, MODE_MFMA, PRO_RMSNORM>();

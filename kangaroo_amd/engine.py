@@ -200,16 +200,18 @@ class KangarooEngine:
         _lib.check(self.lib.kg_adapter_forward(self._handle, _ptr(x_in), pos0, n_rows, _ptr(out), _stream()), "kg_adapter_forward")
         return out
 
-    def head_logits(self, x: torch.Tensor, want_stats: bool = False):
+    def head_logits(self, x: torch.Tensor, want_stats: bool = False, verify_arithmetic: bool = False):
+        """verify_arithmetic: a single row goes through the multi-row (MFMA) kernel, bit-identical to that row inside a verify pass."""
         n = x.shape[0]
+        nr = -1 if (verify_arithmetic and n == 1) else n
         x = x.to(self.dtype).contiguous()
         logits = torch.empty((n, self.shape.vocab_size), dtype=self.dtype, device=self.device)
         if want_stats:
             am = torch.empty(n, dtype=torch.int32, device=self.device)
             pm = torch.empty(n, dtype=torch.float32, device=self.device)
-            _lib.check(self.lib.kg_head_logits(self._handle, _ptr(x), n, _ptr(logits), _ptr(am), _ptr(pm), _stream()), "kg_head_logits")
+            _lib.check(self.lib.kg_head_logits(self._handle, _ptr(x), nr, _ptr(logits), _ptr(am), _ptr(pm), _stream()), "kg_head_logits")
             return logits, am, pm
-        _lib.check(self.lib.kg_head_logits(self._handle, _ptr(x), n, _ptr(logits), None, None, _stream()), "kg_head_logits")
+        _lib.check(self.lib.kg_head_logits(self._handle, _ptr(x), nr, _ptr(logits), None, None, _stream()), "kg_head_logits")
         return logits
 
     def set_tokens(self, ids: torch.Tensor, pos0: int):

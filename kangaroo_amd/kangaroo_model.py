@@ -31,6 +31,9 @@ class HeadModel:
 
     def __init__(self, engine: KangarooEngine):
         self.engine = engine
+        # True: a lone row is computed by the multi-row kernel, i.e. exactly as a row of a verify pass; plain decoding
+        # driven pass by pass (no draft steps) sets it so that its tokens equal the Kangaroo loop's bit for bit
+        self.single_rows_in_verify_arithmetic = False
 
     def eval(self):
         return self
@@ -43,7 +46,7 @@ class HeadModel:
         e = self.engine
         lead = hidden.shape[:-1]
         x = hidden.reshape(-1, hidden.shape[-1])
-        rows = [e.head_logits(x[i:i + 16]) for i in range(0, x.shape[0], 16)]
+        rows = [e.head_logits(x[i:i + 16], verify_arithmetic=self.single_rows_in_verify_arithmetic) for i in range(0, x.shape[0], 16)]
         return torch.cat(rows, 0).reshape(*lead, e.shape.vocab_size)
 
     forward = __call__
