@@ -16,19 +16,20 @@ eng = model.engine
 for kv in [a for a in sys.argv[1:] if "=" in a]:
     k, v = kv.split("=")
     eng.set_tuning(**{k: int(v)})
-for op in ("qkv", "o", "gateup", "down", "head"):
+for op in (() if "--short" in sys.argv else ("qkv", "o", "gateup", "down", "head")):
     r = []
     for rows in (1, 7):
         us, nb = eng.bench_op(op, rows, iters=2 * shape.num_hidden_layers)
         r.append(f"rows{rows} {us:6.2f} us {nb / us / 1e3:6.0f} GB/s")
     print(f"{op:7s} " + "   ".join(r), flush=True)
+short = "--short" in sys.argv        # one prompt, few tokens, no per-kernel loop: for counter passes
 if "--decode" in sys.argv:
     g = torch.Generator().manual_seed(1)
-    for plen in (64, 600, 1200):
+    for plen in ((64,) if short else (64, 600, 1200)):
         ids = torch.randint(3, shape.vocab_size, (plen,), generator=g)
         eng.generate(ids, 16, mode="kangaroo")
-        out, st = eng.generate(ids, 512, mode="kangaroo")
+        out, st = eng.generate(ids, 64 if short else 512, mode="kangaroo")
         nb = sum((d + 1) * L * shape.layer_weight_bytes() + d * (shape.attn_only_weight_bytes() + shape.head_weight_bytes())
                  + (shape.num_hidden_layers - L) * shape.layer_weight_bytes() + shape.head_weight_bytes() for d in st.draft_lengths)
         print(f"T0={plen:5d} new={st.new_tokens} decode={st.decode_ms:8.1f} ms  {(st.new_tokens - 1) / st.decode_ms * 1e3:7.1f} tok/s  accept {sum(st.accept_lengths) / len(st.accept_lengths):.2f} "
-              f"draft {sum(st.draft_lengths) / len(st.draft_lengths):.2f}  us/round {st.decode_ms * 1e3 / st.rounds:7.1f}  loop {nb / st.decode_ms / 1e6:6.0f} GB/s = {nb / st.decode_ms / 1e6 / 8000:.4f}", flush=True)
+              f"draft {sum(st.draft_lengths) / len(st.draft_lengths):.2f}  us/round {st.decode_ms * 1e3 / st.rounds:7.1f}  loop {nb / st.decode_ms / 1e6:6.0f} GB/s = {nb / st.decode_ms / 1e6 / 8000:.4f}  ids {int(torch.as_tensor(out).long().sum())}", flush=True)
