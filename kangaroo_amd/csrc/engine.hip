@@ -709,13 +709,16 @@ static int capture(kg_session* s, int mode, int steps, hipGraphExec_t* out) {
 
 // One decoder layer on the <= KG_GEMM_ROWS rows described by dyn, through the prefill GEMM
 // kernels; in place on h.  lw.wgu == NULL: attention half only (the adapter layer).
+// xn_ready: pf_xn already holds RMSNorm(h_in) with this layer's norm1 (left there by the previous layer's
+// last projection); next_norm1: the gamma the layer's last projection should do the same with for the next layer.
 static int run_layer_gemm(kg_session* s, const kg_layer_weights& lw, void* kc, void* vc, const KgDyn* dyn,
-                          const void* h_in, void* h_out, hipStream_t st) {
+                          const void* h_in, void* h_out, hipStream_t st, bool xn_ready = false, const void* next_norm1 = nullptr) {
     const kg_shape& sh = s->sh;
     const int d = sh.hidden_size, F = sh.intermediate_size, dt = sh.dtype;
-    // The norms run as kernels of their own here (the pass's rows are normalised once instead of once per
-    // block that stages them), in the reference's order: normalise, round, scale (adapter.py:254-259).
-    KG_TRY(kg_launch_rmsnorm(dyn, h_in, d, lw.norm1, sh.rms_eps, d, s->pf_xn, d, dt, st));
+    // The pass's rows are normalised once (not once per block that stages them), in the reference's order:
+    // normalise, round, scale (adapter.py:254-259); where a projection's K ranges are summed by a kernel of
+    // their own, that kernel also normalises the finished rows for the next projection.
+    if (!xn_ready) KG_TRY(kg_launch_rmsnorm(dyn, h_in, d, lw.norm1, sh.rms_eps, d, s->pf_xn, d, dt, st));
     {
         KgLinArgs a = lin_base(dyn, lw.wqkv, s->q_dim + 2 * s->kv_dim, d, s->pf_xn, d);
         a.q_out = s->pf_xq; a.k_cache = kc; a.v_cache = vc;
@@ -735,10 +738,10 @@ static int run_layer_gemm(kg_session* s, const kg_layer_weights& lw, void* kc, v
     {
         KgLinArgs a = lin_base(dyn, lw.wo, d, s->q_dim, s->pf_ao, s->q_dim);
         a.out = h_out; a.out_stride = d; a.resid = h_in; a.resid_stride = d; a.kpart = s->pf_part;
+        if (lw.wgu != nullptr) { a.out_norm_w = lw.norm2; a.out_norm = s->pf_xn; a.eps = sh.rms_eps; }
         KG_TRY(kg_launch_gemm(a, dt, PRO_NONE, EPI_RESID, st));
     }
     if (lw.wgu == nullptr) return 0;
-    KG_TRY(kg_launch_rmsnorm(dyn, h_out, d, lw.norm2, sh.rms_eps, d, s->pf_xn, d, dt, st));
     {
         KgLinArgs a = lin_base(dyn, lw.wgu, 2 * F, d, s->pf_xn, d);
         a.out = s->pf_act; a.out_stride = F;
@@ -747,6 +750,7 @@ static int run_layer_gemm(kg_session* s, const kg_layer_weights& lw, void* kc, v
     {
         KgLinArgs a = lin_base(dyn, lw.wdown, d, F, s->pf_act, F);
         a.out = h_out; a.out_stride = d; a.resid = h_out; a.resid_stride = d; a.kpart = s->pf_part;
+        if (next_norm1) { a.out_norm_w = next_norm1; a.out_norm = s->pf_xn; a.eps = sh.rms_eps; }
         KG_TRY(kg_launch_gemm(a, dt, PRO_NONE, EPI_RESID, st));
     }
     return 0;
@@ -769,7 +773,7 @@ static int prefill(kg_session* s, int T0, bool with_adapter, hipStream_t st) {
         const void* cur = hb;
         for (int l = 0; l < N; ++l) {
             void* dst = (l == L - 1) ? (void*)(s->hs_early + (size_t)c0 * rowb) : (void*)hb;
-            if (gemm) KG_TRY(run_layer_gemm(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_call, cur, dst, st));
+            if (gemm) KG_TRY(run_layer_gemm(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_call, cur, dst, st, l > 0, l + 1 < N ? s->layers[l + 1].norm1 : nullptr));
             else KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_call, C, cur, dst, st));
             cur = dst;
         }

@@ -4,9 +4,10 @@
 // decode kernels streams them T0/16 times.  Here a pass carries 128 rows, so the weights are
 // read T0/128 times.
 //
-// Same packed weight tiles as the decode kernels.  A wave owns one 16-row group of W and
-// walks all of K: per k-batch of 4 tiles it holds the A fragments in registers (a ring of four
-// batches, three in flight) and multiplies them with eight 16-row column blocks of X^T from LDS.  X^T is
+// Same packed weight tiles as the decode kernels.  A wave owns one or two adjacent 16-row groups of W and
+// walks all of K: per k-batch of 4 tiles it holds their A fragments in registers (a ring of batches, all
+// but one in flight) and multiplies them with eight 16-row column blocks of X^T from LDS; with two row
+// groups every X^T fragment read from LDS feeds both.  X^T is
 // staged batch by batch (128 rows x 128 k, double-buffered, XOR-swizzled) by four extra LOADER waves
 // of the block (rows that need an RMSNorm are normalised by kg_rmsnorm_kernel beforehand, once per pass
 // instead of once per block).  The split matters because a wave's loads retire in order: a wave that both
@@ -28,7 +29,10 @@ static_assert(GEMM_KB == 4, "the LDS swizzle assumes 256-byte rows");
 
 // GEMM_NW = waves (= weight row groups) per block: 4 shares one staged X batch among more
 // row groups; 2 keeps 128 blocks for the 4096-row projections.
-template <int DT, int EPI, int GEMM_NW>
+// GEMM_RPW = weight row groups per compute wave: 2 halves the LDS reads per MFMA; 1 leaves registers for a
+// deeper ring of weight batches (more bytes in flight per wave), which is what counts when the row groups
+// are too few to fill the CUs with two-group waves.
+template <int DT, int EPI, int GEMM_NW, int GEMM_RPW>
 __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const KgLinArgs a) {
     constexpr int GEMM_STAGE = KG_GEMM_ROWS * (GEMM_KB * 4) / (GEMM_LW * 64);    // 16-byte pieces of a batch each loader thread stages
     constexpr int PPR = GEMM_KB * 4;                                   // 16-byte pieces per X row of a batch
@@ -44,7 +48,7 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
     const int G = (a.N + 15) >> 4, KT = a.K >> 5, NB = (KT + GEMM_KB - 1) / GEMM_KB;
     const bool loader = wave >= GEMM_NW;               // wave-uniform role
     const int ltid = tid - GEMM_NW * 64;               // loader thread index (negative in compute waves)
-    const int rg = blockIdx.x * GEMM_NW + (loader ? 0 : wave);     // >= G in the last block: loads out of range, nothing stored
+    const int rg0 = (blockIdx.x * GEMM_NW + (loader ? 0 : wave)) * GEMM_RPW;     // >= G in the last block: loads out of range, nothing stored
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs0 = smem;
     char* xs1 = smem + KG_GEMM_ROWS * GEMM_XROW;
@@ -59,13 +63,16 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
     const int kb0 = (int)(((long long)NB * blockIdx.y) / KS), NBL = (int)(((long long)NB * (blockIdx.y + 1)) / KS) - kb0;
     const int bstart = NBL > 0 ? (int)((blockIdx.x * 5u) % (unsigned)NBL) : 0;
     auto kbatch = [&](int step) { int b = step + bstart; if (b >= NBL) b -= NBL; return (step < NBL) ? kb0 + b : NB; };   // NB: out of range
-    auto issue_w = [&](kg_u4 (&wv)[GEMM_KB], int step) {
+    auto issue_w = [&](kg_u4 (&wv)[GEMM_RPW][GEMM_KB], int step) {
         const int b = kbatch(step);
-        const unsigned base = (unsigned)rg * (unsigned)KT * 1024u + (unsigned)lane * 16u;
 #pragma unroll
-        for (int u = 0; u < GEMM_KB; ++u) {
-            const bool ok = (rg < G) && (GEMM_KB * b + u < KT);
-            wv[u] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, ok ? base + (unsigned)(GEMM_KB * b + u) * 1024u : 0xFFFFFFFFu, 0, 2);
+        for (int j = 0; j < GEMM_RPW; ++j) {
+            const unsigned base = (unsigned)(rg0 + j) * (unsigned)KT * 1024u + (unsigned)lane * 16u;
+#pragma unroll
+            for (int u = 0; u < GEMM_KB; ++u) {
+                const bool ok = (rg0 + j < G) && (GEMM_KB * b + u < KT);
+                wv[j][u] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, ok ? base + (unsigned)(GEMM_KB * b + u) * 1024u : 0xFFFFFFFFu, 0, 2);
+            }
         }
     };
     // staging: piece q = tid + nthreads * j covers row q / PPR, 16-byte column q % PPR of the batch
@@ -85,30 +92,51 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
         for (int j = 0; j < GEMM_STAGE; ++j) *(kg_u4*)(xs + GEMM_XOFF(srow0 + RPJ * j, scol)) = sx[j];
     };
 
-    kg_f4 acc[KG_GEMM_ROWS / 16];
+    kg_f4 acc[GEMM_RPW][KG_GEMM_ROWS / 16];
 #pragma unroll
-    for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) acc[cb] = kg_f4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < GEMM_RPW; ++j)
+#pragma unroll
+        for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) acc[j][cb] = kg_f4{0.f, 0.f, 0.f, 0.f};
     // All column blocks always run (rows past M are zeros in LDS): a branch per block would
     // put every LDS read right in front of its MFMA with a full wait in between.
-    auto compute = [&](const kg_u4 (&wv)[GEMM_KB], const char* xs) {
-        kg_u4 x[GEMM_KB][KG_GEMM_ROWS / 16];
+    auto load_x = [&](kg_u4 (&x)[KG_GEMM_ROWS / 16], const char* xs, int u) {
 #pragma unroll
-        for (int u = 0; u < GEMM_KB; ++u)
+        for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) x[cb] = *(const kg_u4*)(xs + GEMM_XOFF(16 * cb + r, 4 * u + g));
+    };
+    auto compute = [&](const kg_u4 (&wv)[GEMM_RPW][GEMM_KB], const char* xs) {
+        if (GEMM_RPW == 1) {
+            // one row group: every fragment feeds one MFMA, so all of a batch's fragments are requested at once
+            kg_u4 x[GEMM_KB][KG_GEMM_ROWS / 16];
 #pragma unroll
-            for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) x[u][cb] = *(const kg_u4*)(xs + GEMM_XOFF(16 * cb + r, 4 * u + g));
+            for (int u = 0; u < GEMM_KB; ++u) load_x(x[u], xs, u);
 #pragma unroll
-        for (int u = 0; u < GEMM_KB; ++u)
+            for (int u = 0; u < GEMM_KB; ++u)
 #pragma unroll
-            for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) acc[cb] = T::mfma(wv[u], x[u][cb], acc[cb]);
+                for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) acc[0][cb] = T::mfma(wv[0][u], x[u][cb], acc[0][cb]);
+        } else {
+            // two row groups: the fragments of two k tiles at a time (registers), each feeding two MFMAs
+#pragma unroll
+            for (int h = 0; h < GEMM_KB / 2; ++h) {
+                kg_u4 x[2][KG_GEMM_ROWS / 16];
+                load_x(x[0], xs, 2 * h);
+                load_x(x[1], xs, 2 * h + 1);
+#pragma unroll
+                for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+                    for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb)
+#pragma unroll
+                        for (int j = 0; j < GEMM_RPW; ++j) acc[j][cb] = T::mfma(wv[j][2 * h + uu], x[uu][cb], acc[j][cb]);
+            }
+        }
     };
 
     // Software pipeline, one block barrier per k-batch.  Compute waves: ring of D register batches of
     // weights, all but one in flight.  Loader waves: X(b) sits in LDS buffer b & 1; X(b+1) .. X(b+XS)
     // are on their way in XS register sets; during step b the set holding X(b+1) goes to the other
     // LDS buffer and is re-requested for X(b+1+XS).
-    constexpr int D = 4;
-    constexpr int XS = 4;
-    constexpr int U = 4;                                // steps per unrolled round: a multiple of D, XS and 2
+    constexpr int D = (GEMM_RPW == 2) ? 3 : 4;
+    constexpr int XS = (GEMM_RPW == 2) ? 3 : 4;
+    constexpr int U = (GEMM_RPW == 2) ? 6 : 4;          // steps per unrolled round: a multiple of D, XS and 2
     static_assert(U % D == 0 && U % XS == 0 && U % 2 == 0, "ring indices must repeat every unrolled round");
 #ifdef KG_LIN_TLOG
     unsigned long long tl_issue = 0, tl_compute = 0, tl_store = 0, tl_barrier = 0;
@@ -127,6 +155,7 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
 #pragma unroll
             for (int i = 0; i < U; ++i) {
                 const int bb = b + i;
+                if (bb >= NBL) break;                   // block-uniform: both roles leave after the same barrier
 #ifdef KG_LIN_TLOG
                 unsigned long long tl0 = wall_clock64();
 #endif
@@ -139,15 +168,16 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
             }
         }
     } else {
-        kg_u4 w[D][GEMM_KB];
+        kg_u4 w[D][GEMM_RPW][GEMM_KB];
 #pragma unroll
         for (int i = 0; i < D - 1; ++i) issue_w(w[i], i);
         __syncthreads();
         KG_TSTAMP(a, 1);
-        for (int b = 0; b < NBL; b += U) {      // batches past the last one: zeros in, zeros added
+        for (int b = 0; b < NBL; b += U) {
 #pragma unroll
             for (int i = 0; i < U; ++i) {
                 const int bb = b + i;
+                if (bb >= NBL) break;
 #ifdef KG_LIN_TLOG
                 unsigned long long tl0 = wall_clock64();
 #endif
@@ -172,30 +202,33 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
     }
 #endif
     // ---- epilogue inputs through LDS (the X buffers are free now), laid out as the decode epilogues expect ----
-    char* side = (EPI == EPI_RESID) ? xs0 + (size_t)(loader ? 0 : wave) * KG_GEMM_ROWS * 32 : xs0;
     if (EPI == EPI_RESID && KS > 1) {
         // partial sums of this K range; kg_gemm_reduce_kernel adds the ranges and the residual
-        if (loader || rg >= G) return;
+        if (loader) return;
         float* part = a.kpart + (size_t)blockIdx.y * KG_GEMM_ROWS * a.N;
 #pragma unroll
-        for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) {
-            const int m = 16 * cb + r;
-            if (m < M) {
+        for (int j = 0; j < GEMM_RPW; ++j) {
+            if (rg0 + j >= G) break;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int n = rg * 16 + 4 * g + i;
-                    if (n < a.N) part[(size_t)m * a.N + n] = acc[cb][i];
+            for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) {
+                const int m = 16 * cb + r;
+                if (m < M) {
+                    const int n = (rg0 + j) * 16 + 4 * g;          // N is a multiple of 16 on this path (the launcher checks)
+                    *(kg_f4*)(part + (size_t)m * a.N + n) = acc[j][cb];
                 }
             }
         }
         return;
     }
+    char* side = (EPI == EPI_RESID) ? xs0 + (size_t)(loader ? 0 : wave) * GEMM_RPW * KG_GEMM_ROWS * 32 : xs0;
     if (EPI == EPI_RESID && !loader) {
         const unsigned short* res = (const unsigned short*)a.resid;
-        for (int e = lane; e < M * 16; e += 64) {
-            const int m = e >> 4, n = rg * 16 + (e & 15);
-            ((unsigned short*)side)[e] = (n < a.N) ? res[(size_t)m * a.resid_stride + n] : (unsigned short)0;
-        }
+#pragma unroll
+        for (int j = 0; j < GEMM_RPW; ++j)
+            for (int e = lane; e < M * 16; e += 64) {
+                const int m = e >> 4, n = (rg0 + j) * 16 + (e & 15);
+                ((unsigned short*)side)[j * KG_GEMM_ROWS * 16 + e] = (n < a.N) ? res[(size_t)m * a.resid_stride + n] : (unsigned short)0;
+            }
     } else if (EPI == EPI_ROPE_KV) {
         const int half = a.head_dim >> 1;
         for (int i = tid; i < M * a.head_dim; i += (GEMM_NW + GEMM_LW) * 64) {
@@ -205,15 +238,21 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
         }
     }
     __syncthreads();
-    if (loader || rg >= G) { KG_TSTAMP(a, 7); return; }
+    if (loader) { KG_TSTAMP(a, 7); return; }
     HeadRun run; run.mx = -INFINITY; run.sum = 0.f; run.idx = 0;
 #pragma unroll
-    for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) {
-        const int m = 16 * cb + r;
-        if (m < M) {
-            // lane holds D[weight row 4g + i][column m], i = 0..3: two adjacent-row pairs
-            epilogue_pair<DT, EPI, false>(a, rg * 16 + 4 * g, m, pos0 + m, acc[cb][0], acc[cb][1], run, side, 0, M);
-            epilogue_pair<DT, EPI, false>(a, rg * 16 + 4 * g + 2, m, pos0 + m, acc[cb][2], acc[cb][3], run, side, 0, M);
+    for (int j = 0; j < GEMM_RPW; ++j) {
+        const int rg = rg0 + j;
+        if (rg >= G) break;
+        const char* sj = (EPI == EPI_RESID) ? side + (size_t)j * KG_GEMM_ROWS * 32 : side;
+#pragma unroll
+        for (int cb = 0; cb < KG_GEMM_ROWS / 16; ++cb) {
+            const int m = 16 * cb + r;
+            if (m < M) {
+                // lane holds D[weight row 4g + i][column m], i = 0..3: two adjacent-row pairs
+                epilogue_pair<DT, EPI, false>(a, rg * 16 + 4 * g, m, pos0 + m, acc[j][cb][0], acc[j][cb][1], run, sj, 0, M);
+                epilogue_pair<DT, EPI, false>(a, rg * 16 + 4 * g + 2, m, pos0 + m, acc[j][cb][2], acc[j][cb][3], run, sj, 0, M);
+            }
         }
     }
     KG_TSTAMP(a, 7);
@@ -242,41 +281,114 @@ __global__ void kg_gemm_reduce_kernel(const KgLinArgs a) {
     for (int i = 0; i < 4; ++i) out[n + i] = T::from_f(T::to_f(res[n + i]) + kg_round<DT>(v[i]));
 }
 
+// The same sum, one block per row, followed by the RMSNorm of the finished row for the next projection
+// (a.out_norm_w / a.out_norm): out as above, out_norm[m][n] = round16(gamma[n] * round16(out[m][n] * rstd)).
+// Thread t owns the 8-column pieces t, t + 256, ... in both halves, exactly as kg_rmsnorm_kernel does, so the
+// result is bit-identical to kg_gemm_reduce_kernel followed by kg_rmsnorm_kernel.
+template <int DT>
+__global__ void __launch_bounds__(256) kg_gemm_reduce_norm_kernel(const KgLinArgs a) {
+    typedef KgT<DT> T;
+    const KgDyn* dyn = a.dyn;
+    if (dyn->active == 0) return;
+    const int m = blockIdx.x;
+    if (m >= dyn->n_rows) return;
+    __shared__ float red[4];
+    const unsigned short* res = (const unsigned short*)a.resid + (size_t)m * a.resid_stride;
+    unsigned short* out = (unsigned short*)a.out + (size_t)m * a.out_stride;
+    unsigned short* xn = (unsigned short*)a.out_norm + (size_t)m * a.N;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < (a.N >> 3); i += 256) {
+        const int n = 8 * i;
+        kg_f4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        kg_f4 p[4], q[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float* pp = a.kpart + ((size_t)s * KG_GEMM_ROWS + m) * a.N + n;
+            p[s] = (s < a.ksplit) ? *(const kg_f4*)pp : lo;
+            q[s] = (s < a.ksplit) ? *(const kg_f4*)(pp + 4) : hi;
+        }
+        lo = ((p[0] + p[1]) + p[2]) + p[3];
+        hi = ((q[0] + q[1]) + q[2]) + q[3];
+        const kg_us8 r8 = __builtin_bit_cast(kg_us8, *(const kg_u4*)(res + n));
+        kg_us8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = T::from_f(T::to_f(r8[e]) + kg_round<DT>(e < 4 ? lo[e] : hi[e - 4]));
+            const float f = T::to_f(o[e]);
+            ss += f * f;
+        }
+        *(kg_u4*)(out + n) = __builtin_bit_cast(kg_u4, o);
+    }
+    ss = kg_wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
+    const float rstd = rsqrtf(ss / (float)a.N + a.eps);
+    for (int i = threadIdx.x; i < (a.N >> 3); i += 256) {
+        const kg_us8 h = __builtin_bit_cast(kg_us8, *(const kg_u4*)(out + 8 * i));          // this thread's own stores
+        const kg_us8 g = __builtin_bit_cast(kg_us8, ((const kg_u4*)a.out_norm_w)[i]);
+        kg_us8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = T::from_f(T::to_f(g[e]) * kg_round<DT>(T::to_f(h[e]) * rstd));
+        *(kg_u4*)(xn + 8 * i) = __builtin_bit_cast(kg_u4, o);
+    }
+}
+
 static int g_gemm_ncu = 256;
+static void gemm_geometry(int G, int ks, int* nw_out, int* rpw_out);
+// blocks on grid.x of a pass over N output rows (tools that index per-block records need it)
+int kg_gemm_grid_x(int N, int ksplit) {
+    int nw = 2, rpw = 2;
+    const int G = (N + 15) / 16;
+    gemm_geometry(G, ksplit > 1 ? ksplit : 1, &nw, &rpw);
+    return (G + nw * rpw - 1) / (nw * rpw);
+}
 static size_t gemm_smem() { return (size_t)2 * KG_GEMM_ROWS * GEMM_XROW; }
 
-template <int DT, int NW>
+template <int DT, int NW, int RPW>
 static int launch_epi(const KgLinArgs& a, int epi, hipStream_t st) {
     const int G = (a.N + 15) / 16;
-    const dim3 grid((G + NW - 1) / NW, a.ksplit > 1 ? a.ksplit : 1), block((NW + GEMM_LW) * 64);
+    const dim3 grid((G + NW * RPW - 1) / (NW * RPW), a.ksplit > 1 ? a.ksplit : 1), block((NW + GEMM_LW) * 64);
     const size_t smem = gemm_smem();
     switch (epi) {
-    case EPI_STORE: hipLaunchKernelGGL((kg_gemm_kernel<DT, EPI_STORE, NW>), grid, block, smem, st, a); break;
-    case EPI_RESID: hipLaunchKernelGGL((kg_gemm_kernel<DT, EPI_RESID, NW>), grid, block, smem, st, a); break;
-    case EPI_ROPE_KV: hipLaunchKernelGGL((kg_gemm_kernel<DT, EPI_ROPE_KV, NW>), grid, block, smem, st, a); break;
-    case EPI_SILU_MUL: hipLaunchKernelGGL((kg_gemm_kernel<DT, EPI_SILU_MUL, NW>), grid, block, smem, st, a); break;
+    case EPI_STORE: hipLaunchKernelGGL((kg_gemm_kernel<DT, EPI_STORE, NW, RPW>), grid, block, smem, st, a); break;
+    case EPI_RESID: hipLaunchKernelGGL((kg_gemm_kernel<DT, EPI_RESID, NW, RPW>), grid, block, smem, st, a); break;
+    case EPI_ROPE_KV: hipLaunchKernelGGL((kg_gemm_kernel<DT, EPI_ROPE_KV, NW, RPW>), grid, block, smem, st, a); break;
+    case EPI_SILU_MUL: hipLaunchKernelGGL((kg_gemm_kernel<DT, EPI_SILU_MUL, NW, RPW>), grid, block, smem, st, a); break;
     default: return -1;
     }
     return 0;
 }
+// Geometry of a pass: compute waves per block (2..4) and row groups per wave (1 or 2).  Measured over the
+// 7B and 13B projections at 128 rows: the fastest geometry is always the one that finishes in the fewest
+// rounds of blocks and, among those, has the most blocks (every block stages X for itself, but a CU without
+// a block streams nothing); at equal block counts more waves per block win.
+static void gemm_geometry(int G, int ks, int* nw_out, int* rpw_out) {
+    long best_score = -1;
+    for (int rpw = 2; rpw >= 1; --rpw)
+        for (int nw = 4; nw >= 2; --nw) {
+            const int blocks = (G + nw * rpw - 1) / (nw * rpw) * ks;
+            const int rounds = (blocks + g_gemm_ncu - 1) / g_gemm_ncu;
+            const int resident = blocks < g_gemm_ncu ? blocks : g_gemm_ncu;
+            const long score = ((long)(1000 - rounds) << 20) + ((long)resident << 4) + nw;
+            if (score > best_score) { best_score = score; *nw_out = nw; *rpw_out = rpw; }
+        }
+    const char* fn = getenv("KG_GEMM_NW");
+    const char* fr = getenv("KG_GEMM_RPW");
+    if (fn) *nw_out = atoi(fn);
+    if (fr) *rpw_out = atoi(fr);
+}
 template <int DT>
 static int launch_nw(const KgLinArgs& a, int epi, hipStream_t st) {
-    // Row groups per block (= compute waves): a block's step costs about as much LDS and MFMA time as it
-    // has compute waves, and the launch takes ceil(blocks / CUs) rounds of blocks, so pick the count that
-    // minimises rounds x waves (768 groups: 3 -> 256 blocks in one round; 1376: 3 -> two rounds of 3).
-    const int units = ((a.N + 15) / 16);
-    int best = 2, best_cost = 1 << 30;
-    for (int nw = 4; nw >= 2; --nw) {
-        const int blocks = (units + nw - 1) / nw * (a.ksplit > 1 ? a.ksplit : 1);
-        const int cost = ((blocks + g_gemm_ncu - 1) / g_gemm_ncu) * nw;
-        if (cost < best_cost) { best_cost = cost; best = nw; }
-    }
-    const char* force = getenv("KG_GEMM_NW");
-    if (force) best = atoi(force);
-    switch (best) {
-    case 4: return launch_epi<DT, 4>(a, epi, st);
-    case 3: return launch_epi<DT, 3>(a, epi, st);
-    default: return launch_epi<DT, 2>(a, epi, st);
+    int nw = 2, rpw = 2;
+    gemm_geometry((a.N + 15) / 16, a.ksplit > 1 ? a.ksplit : 1, &nw, &rpw);
+    switch (nw * 10 + rpw) {
+    case 42: return launch_epi<DT, 4, 2>(a, epi, st);
+    case 32: return launch_epi<DT, 3, 2>(a, epi, st);
+    case 22: return launch_epi<DT, 2, 2>(a, epi, st);
+    case 41: return launch_epi<DT, 4, 1>(a, epi, st);
+    case 31: return launch_epi<DT, 3, 1>(a, epi, st);
+    default: return launch_epi<DT, 2, 1>(a, epi, st);
     }
 }
 
@@ -297,26 +409,37 @@ int kg_launch_gemm(const KgLinArgs& a_in, int dtype, int pro, int epi, hipStream
     if (pro != PRO_NONE) return -1;          // rows are normalised by kg_launch_rmsnorm before the pass
     rc = (dtype == KG_F16) ? launch_nw<KG_F16>(a, epi, st) : launch_nw<KG_BF16>(a, epi, st);
     if (rc) return rc;
+    const bool norm_after = (a.out_norm_w != nullptr && a.out_norm != nullptr);
+    if (norm_after && epi != EPI_RESID) return -1;
+    if (a.ksplit > 1 && norm_after) {
+        if (dtype == KG_F16) hipLaunchKernelGGL(kg_gemm_reduce_norm_kernel<KG_F16>, dim3(KG_GEMM_ROWS), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(kg_gemm_reduce_norm_kernel<KG_BF16>, dim3(KG_GEMM_ROWS), dim3(256), 0, st, a);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     if (a.ksplit > 1) {
         const dim3 grid((a.N / 4 + 255) / 256, KG_GEMM_ROWS);
         if (dtype == KG_F16) hipLaunchKernelGGL(kg_gemm_reduce_kernel<KG_F16>, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(kg_gemm_reduce_kernel<KG_BF16>, grid, dim3(256), 0, st, a);
     }
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    if (hipGetLastError() != hipSuccess) return -2;
+    if (norm_after) return kg_launch_rmsnorm(a.dyn, a.out, a.out_stride, a.out_norm_w, a.eps, a.N, a.out_norm, a.N, dtype, st);
+    return 0;
 }
 
-template <int DT, int NW> static void set_attr_all() {
+template <int DT, int NW, int RPW> static void set_attr_all() {
     const int lim = (int)gemm_smem();
-    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, EPI_STORE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, EPI_RESID, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, EPI_ROPE_KV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, EPI_SILU_MUL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, EPI_STORE, NW, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, EPI_RESID, NW, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, EPI_ROPE_KV, NW, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute((const void*)kg_gemm_kernel<DT, EPI_SILU_MUL, NW, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+}
+template <int DT> static void set_attr_dt() {
+    set_attr_all<DT, 2, 1>(); set_attr_all<DT, 3, 1>(); set_attr_all<DT, 4, 1>();
+    set_attr_all<DT, 2, 2>(); set_attr_all<DT, 3, 2>(); set_attr_all<DT, 4, 2>();
 }
 void kg_gemm_init() {
     int dev = 0, ncu = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) g_gemm_ncu = ncu;
-    set_attr_all<KG_F16, 2>(); set_attr_all<KG_BF16, 2>();
-    set_attr_all<KG_F16, 3>(); set_attr_all<KG_BF16, 3>();
-    set_attr_all<KG_F16, 4>(); set_attr_all<KG_BF16, 4>();
+    set_attr_dt<KG_F16>(); set_attr_dt<KG_BF16>();
     (void)hipGetLastError();
 }

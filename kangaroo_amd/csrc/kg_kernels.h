@@ -29,6 +29,9 @@ struct KgLinArgs {
     // prefill GEMM, EPI_RESID with few row groups: K cut into ksplit ranges on grid.y, fp32 partials
     // [ksplit][KG_GEMM_ROWS][N] summed in range order by a second kernel (0 / NULL: one range)
     float* kpart; int ksplit;
+    // prefill GEMM, EPI_RESID: RMSNorm (gamma out_norm_w, a.eps) of the finished output rows for the next
+    // projection, written to out_norm [rows][N] (NULL: none)
+    const void* out_norm_w; void* out_norm;
 };
 
 size_t kg_linear_smem(int mfma, int max_rows, int K, int nwaves);

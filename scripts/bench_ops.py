@@ -23,6 +23,14 @@ for op in (() if "--short" in sys.argv else ("qkv", "o", "gateup", "down", "head
         r.append(f"rows{rows} {us:6.2f} us {nb / us / 1e3:6.0f} GB/s")
     print(f"{op:7s} " + "   ".join(r), flush=True)
 short = "--short" in sys.argv        # one prompt, few tokens, no per-kernel loop: for counter passes
+if "--prefill" in sys.argv:
+    g = torch.Generator().manual_seed(2)
+    for plen in (128, 640, 1500):
+        ids = torch.randint(3, shape.vocab_size, (plen,), generator=g)
+        eng.generate(ids, 2, mode="kangaroo")
+        ms = [eng.generate(ids, 2, mode="kangaroo")[1].prefill_ms for _ in range(3)]
+        print(f"prefill T0={plen:5d}: {min(ms):7.2f} ms  ({2 * shape.param_count() * plen / min(ms) / 1e9:6.0f} TFLOP/s)" if hasattr(shape, "param_count")
+              else f"prefill T0={plen:5d}: {min(ms):7.2f} ms", flush=True)
 if "--decode" in sys.argv:
     g = torch.Generator().manual_seed(1)
     for plen in ((64,) if short else (64, 600, 1200)):

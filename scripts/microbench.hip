@@ -210,6 +210,39 @@ int main(int argc, char** argv) {
             }
         }
     }
+    if (what == "gemm") {
+        // 128-row prefill passes at the 7B shapes, 16 launches per graph over rotating weights
+        kg_gemm_init();
+        const int rows = argc > 2 ? atoi(argv[2]) : 128;
+        KgDyn* dynr; CK(hipMalloc(&dynr, sizeof(KgDyn)));
+        CK(kg_launch_set_dyn(dynr, 1, rows, 0, st) == 0 ? hipSuccess : hipErrorUnknown);
+        char* xr; CK(hipMalloc(&xr, (size_t)KG_GEMM_ROWS * 16384 * 2)); CK(hipMemset(xr, 0, (size_t)KG_GEMM_ROWS * 16384 * 2));
+        char* outr; CK(hipMalloc(&outr, (size_t)KG_GEMM_ROWS * 32768 * 2));
+        char* resr; CK(hipMalloc(&resr, (size_t)KG_GEMM_ROWS * 32768 * 2)); CK(hipMemset(resr, 0, (size_t)KG_GEMM_ROWS * 32768 * 2));
+        float* kp; CK(hipMalloc(&kp, (size_t)4 * KG_GEMM_ROWS * 8192 * 4));
+        struct { const char* name; int N, K, epi; } cfg[] = {{"qkv-like store", 12288, 4096, EPI_STORE}, {"o", 4096, 4096, EPI_RESID}, {"gateup", 22016, 4096, EPI_SILU_MUL},
+                                                            {"down", 4096, 11008, EPI_RESID}, {"gateup 13B", 27648, 5120, EPI_SILU_MUL}, {"down 13B", 5120, 13824, EPI_RESID}};
+        for (auto& c : cfg) {
+            const int nlaunch = 16;
+            const size_t bytes = (size_t)c.N * c.K * 2;
+            hipGraphExec_t ge = capture(st, [&]() {
+                size_t off = 0;
+                for (int i = 0; i < nlaunch; ++i) {
+                    if (off + bytes > pool_bytes) off = 0;
+                    KgLinArgs a; memset(&a, 0, sizeof(a));
+                    a.W = pool + off; a.N = c.N; a.K = c.K; a.dyn = dynr; a.x = xr; a.x_stride = c.K;
+                    a.out = outr; a.out_stride = c.epi == EPI_SILU_MUL ? c.N / 2 : c.N; a.resid = resr; a.resid_stride = c.N; a.kpart = kp;
+                    if (kg_launch_gemm(a, KG_F16, PRO_NONE, c.epi, st) != 0) printf("launch refused\n");
+                    off += bytes;
+                }
+            });
+            float ms = time_graph(st, ge, 3) / nlaunch;
+            printf("gemm %-15s rows %3d: %6.1f us per pass  %5.0f GB/s of weights  %5.0f TFLOP/s\n", c.name, rows, ms * 1e3, bytes / (ms * 1e-3) / 1e9,
+                   2.0 * rows * c.N * c.K / (ms * 1e-3) / 1e12);
+            CK(hipGraphExecDestroy(ge));
+        }
+        return 0;
+    }
     if (what == "gemm_timeline") {
         // 16 back-to-back 64-row GEMM passes (gate/up shape, then down shape): per block, the time spent
         // in each part of a pipeline step, summed over the steps
@@ -222,7 +255,7 @@ int main(int argc, char** argv) {
         for (auto& c : cfg) {
             const int nlaunch = 16;
             const size_t bytes = (size_t)c.N * c.K * 2;
-            const int G = c.N / 16, nw_ = (G >= 512) ? 4 : 2, nb = (G + nw_ - 1) / nw_;
+            const int nb = kg_gemm_grid_x(c.N, 1), nw_ = (c.N / 16 + nb - 1) / nb;      // nw_: row groups per block
             hipGraphExec_t ge = capture(st, [&]() {
                 size_t off = 0;
                 for (int i = 0; i < nlaunch; ++i) {
@@ -251,7 +284,7 @@ int main(int argc, char** argv) {
                 printf("   blocks entering more than 10 us after the first: %d of %d\n", late, nb);
             }
             const double n = (double)(nlaunch - 1) * nb * 100.0;      // -> us per block
-            printf("gemm %-15s %.1f us per launch, %d blocks x %d waves; per block: total %.1f us = prologue %.1f + weight issue %.1f + LDS reads/MFMA %.1f + barrier %.1f + epilogue %.1f | loader wave: X wait + LDS store %.1f\n",
+            printf("gemm %-15s %.1f us per launch, %d blocks x %d row groups; per block: total %.1f us = prologue %.1f + weight issue %.1f + LDS reads/MFMA %.1f + barrier %.1f + epilogue %.1f | loader wave: X wait + LDS store %.1f\n",
                    c.name, ms * 1e3, nb, nw_, s_tot / n, s_pro / n, s_issue / n, s_comp / n, s_bar / n, s_epi / n, s_store / n);
             CK(hipGraphExecDestroy(ge));
         }
