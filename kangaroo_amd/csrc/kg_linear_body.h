@@ -294,6 +294,9 @@ template <int DT, int MODE, int PRO, int EPI, bool PERSIST>
 __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, KgGridBar* gb, int nwaves) {
     typedef KgT<DT> T;
     KG_TSTAMP(a, 0);
+#ifdef KG_LIN_TLOG
+    if (threadIdx.x == blockDim.x - 64) kg_lin_tlog[((size_t)a.logits_stride * gridDim.x + blockIdx.x) * 8 + 7] = wall_clock64();     // entry of the block's last wave
+#endif
     constexpr bool COH = PERSIST;                       // outputs: written through to memory
     constexpr bool COH_LD = PERSIST && KG_PERSIST_COH_LOADS; // inputs written by other blocks earlier in this kernel
     const KgDyn* dyn = a.dyn;
@@ -497,6 +500,7 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
     lt += KG_U;
     if (lt >= t1) { lt = t0; lrg += gridDim.x; }
 
+    KG_TSTAMP(a, 5);
     if (side_fast) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -525,6 +529,7 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
         else if (pro_sets == 1) prologue_finish<DT, PRO, NS, RM, 1>(a, pr, xs, xs_stride, red2, M, tid, nthreads, lane, wave, nwaves);
         else prologue_finish<DT, PRO, NS, RM, 2>(a, pr, xs, xs_stride, red2, M, tid, nthreads, lane, wave, nwaves);
     }
+    KG_TSTAMP(a, 6);
     __syncthreads();
     KG_TSTAMP(a, 2);
 

@@ -92,6 +92,12 @@ __global__ void __launch_bounds__(512) k_lin_tl(const KgLinArgs a_in) {
     kg_linear_body<KG_F16, MODE_MFMA, PRO_RMSNORM, EPI_STORE, false>(a, smem, nullptr, blockDim.x >> 6);
 }
 
+// the same for a projection without a norm (o_proj of the verify pass)
+__global__ void __launch_bounds__(512) k_lin_tl_o(const KgLinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    kg_linear_body<KG_F16, MODE_MFMA, PRO_NONE, EPI_STORE, false>(a, smem, nullptr, blockDim.x >> 6);
+}
+
 static float time_graph(hipStream_t st, hipGraphExec_t ge, int reps) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -293,11 +299,13 @@ int main(int argc, char** argv) {
     if (what == "timeline") {
         // 32 back-to-back launches of a gate/up-sized MFMA pass (7 rows) in one graph; per block the
         // stamps are: entry, parameters known, X in LDS, first row group reduced, end.
-        const int N = 22016, K = 4096, nlaunch = 32, nb = 256, nw_ = 8;
+        const bool oproj = argc > 2 && std::string(argv[2]) == "o";       // "o": the 4096 x 4096 projection without a norm
+        const int N = oproj ? 4096 : 22016, K = 4096, nlaunch = 32, nb = oproj ? 256 : 230, nw_ = 8;
         size_t bytes = (size_t)N * K * 2;
         char* xcopies; CK(hipMalloc(&xcopies, (size_t)256 * 16 * K * 2)); CK(hipMemset(xcopies, 0, (size_t)256 * 16 * K * 2));
-        for (int xmode = 0; xmode < 3; ++xmode) {
+        for (int xmode = 0; xmode < (oproj ? 1 : 3); ++xmode) {
         (void)hipFuncSetAttribute((const void*)k_lin_tl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_lin_tl_o, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipGraphExec_t ge = capture(st, [&]() {
             size_t off = 0;
             for (int i = 0; i < nlaunch; ++i) {
@@ -307,7 +315,8 @@ int main(int argc, char** argv) {
                 a.out = out; a.out_stride = N; a.norm_w = nw; a.eps = 1e-6f;
                 a.side_bytes = 512; a.logits_stride = i;
                 const size_t smem = 512 + (size_t)2 * nw_ * 256 * 4 + (size_t)7 * (K * 2 + 32);
-                hipLaunchKernelGGL(k_lin_tl, dim3(nb), dim3(nw_ * 64), smem, st, a);
+                if (oproj) hipLaunchKernelGGL(k_lin_tl_o, dim3(nb), dim3(nw_ * 64), smem, st, a);
+                else hipLaunchKernelGGL(k_lin_tl, dim3(nb), dim3(nw_ * 64), smem, st, a);
                 off += bytes;
             }
         });
@@ -315,28 +324,32 @@ int main(int argc, char** argv) {
         printf("X source %d: timeline kernel %.1f us per launch\n", xmode, ms * 1e3);
         std::vector<unsigned long long> t((size_t)nlaunch * nb * 8);
         CK(hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(kg_lin_tlog), t.size() * 8));
-        double acc[6] = {0, 0, 0, 0, 0, 0};
+        double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         int cnt = 0;
         for (int i = 1; i < nlaunch; ++i) {
             unsigned long long prev_end = 0, first_entry = ~0ull, last_entry = 0, first_end = ~0ull, last_end = 0;
             for (int b = 0; b < nb; ++b) { unsigned long long e = t[((size_t)(i - 1) * nb + b) * 8 + 4]; if (e > prev_end) prev_end = e; }
-            double d1 = 0, d2 = 0, d3 = 0;
+            double d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0, d6 = 0, d7 = 0;
             for (int b = 0; b < nb; ++b) {
                 const unsigned long long* s = &t[((size_t)i * nb + b) * 8];
                 if (s[0] < first_entry) first_entry = s[0];
                 if (s[0] > last_entry) last_entry = s[0];
                 if (s[4] < first_end) first_end = s[4];
                 if (s[4] > last_end) last_end = s[4];
-                d1 += (double)(s[1] - s[0]); d2 += (double)(s[2] - s[1]); d3 += (double)(s[3] - s[2]); 
+                d1 += (double)(s[1] - s[0]); d2 += (double)(s[2] - s[1]); d3 += (double)(s[3] - s[2]); d4 += (double)(s[4] - s[3]);
+                d5 += (double)(s[5] - s[1]); d6 += (double)(s[6] - s[5]); d7 += (double)((long long)(s[7] - s[0]));
             }
             acc[0] += (double)((long long)(first_entry - prev_end)) * 0.01;    // previous kernel's last block end -> this kernel's first block entry
             acc[1] += (double)(last_entry - first_entry) * 0.01;               // entry skew over blocks
             acc[2] += d1 / nb * 0.01; acc[3] += d2 / nb * 0.01; acc[4] += d3 / nb * 0.01;
             acc[5] += (double)(last_end - first_end) * 0.01;                   // end skew over blocks
+            acc[6] += d4 / nb * 0.01; acc[7] += d5 / nb * 0.01; acc[8] += d6 / nb * 0.01; acc[9] += d7 / nb * 0.01;
             ++cnt;
         }
-        printf("gap prev-end -> first entry %.2f us | entry skew %.2f | entry->params %.2f | params->X in LDS %.2f | X->first row group %.2f | end skew %.2f\n",
-               acc[0] / cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[5] / cnt);
+        printf("gap prev-end -> first entry %.2f us | entry skew %.2f | entry->params %.2f | params->X in LDS %.2f | X->first row group reduced %.2f | -> end %.2f | end skew %.2f\n",
+               acc[0] / cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[6] / cnt, acc[5] / cnt);
+        printf("   thread 0 of a block: params -> first two weight batches requested %.2f us | -> its X share in LDS %.2f | -> block barrier passed %.2f | the block's last wave enters %.2f us after its first\n",
+               acc[7] / cnt, acc[8] / cnt, acc[3] / cnt - acc[7] / cnt - acc[8] / cnt, acc[9] / cnt);
         CK(hipGraphExecDestroy(ge));
         }
         return 0;
