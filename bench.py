@@ -316,9 +316,9 @@ def main():
     us, wbytes = eng.bench_op("gateup", rows, iters=4 * shape.num_hidden_layers)
     ach = wbytes / (us * 1e-6) / 1e9
     # HBM bytes per launch from the PMC passes over this same kernel and shape (counters need runs of
-    # their own; profiles/r01_pmc_gateup_rows7.json records command, raw counters and the gfx950 correction)
+    # their own; profiles/r02_pmc_gateup_rows7.json records command, raw counters and the gfx950 correction)
     traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_gateup_rows7.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_gateup_rows7.json")
     if a.model == "vicuna-7b" and rows == 7 and os.path.exists(pmc_file):
         with open(pmc_file) as f:
             traffic = json.load(f).get("hbm_bytes_per_launch")
