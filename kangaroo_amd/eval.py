@@ -144,13 +144,22 @@ def run_eval(model, tokenizer, forward_func: Callable, model_id: str, question_f
              question_end: Optional[int], answer_file: str, max_new_tokens: int, num_choices: int = 1,
              rank: int = 0, world_size: int = 1, **kwargs) -> float:
     """eval.py:20-68.  With world_size > 1 every process (one per GPU) calls this with its rank and gets a
-    contiguous share of the questions, as the reference's worker fan-out cuts them; all append to the same
-    answer file and rank 0 calls reorg_answer_file once every process is done."""
+    contiguous share of the questions, as the reference's worker fan-out cuts them, and all append to the same
+    answer file.  With an initialised torch.distributed process group the ranks meet at a barrier and rank 0
+    then calls reorg_answer_file (the reference does it after ray.get, eval.py:66-68); processes started
+    without a process group leave that call to whoever waits for them."""
     questions = load_questions(question_file, question_begin, question_end)
     mine = shard_prompts(questions, rank, world_size)
     mean_accept = get_model_answers(model, tokenizer, forward_func, model_id, mine, answer_file, max_new_tokens, num_choices, **kwargs)
     if world_size == 1:
         reorg_answer_file(answer_file)
+    else:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+            if rank == 0:
+                reorg_answer_file(answer_file)
+            dist.barrier()
     return mean_accept
 
 

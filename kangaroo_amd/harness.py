@@ -64,8 +64,9 @@ def spec_bench_prompts(vocab_size: int, n: Optional[int] = None, seed: int = 0) 
 
 
 def shard_prompts(prompts: Sequence, rank: int, world: int) -> List:
-    """Contiguous chunks, chunk = len // world, remainder to the last rank: the split the
-    reference's multi-GPU fan-out uses (evaluation/eval.py:50-65)."""
+    """Contiguous chunks of len // world questions, as the reference's multi-GPU fan-out cuts them
+    (evaluation/eval.py:50-65).  The reference's range(0, len, chunk) yields one more task of len % world
+    questions for whichever worker is free; with a fixed process per GPU the last rank takes that remainder."""
     if world <= 1:
         return list(prompts)
     chunk = len(prompts) // world
