@@ -260,6 +260,38 @@ int kg_generate(kg_session* s, int mode, const int32_t* prompt_host, int context
  * [0, rows) and the activation workspace: call it between generations only. */
 int kg_bench_op(kg_session* s, int op, int rows, int iters, float* us_per_launch, size_t* weight_bytes_per_launch);
 
+/* ---- adapter training step (train.py:258-296): the fused, memory-bound pieces ------
+ * The step's matrix products are plain GEMMs over batch x sequence rows and stay with the BLAS library
+ * (kangaroo_amd/train.py); these kernels do everything between them.  Activations are 16-bit (dtype),
+ * statistics / parameters / optimizer state fp32.  All pointers are device pointers. */
+
+/* LlamaRMSNorm forward (kangaroo/adapter.py:254-259) on rows x d: y = round16(gamma * x * rstd); rstd[rows] is kept
+ * for the backward pass. */
+int kg_train_rmsnorm_fwd(int dtype, const void* x, const float* gamma, float eps, int rows, int d, void* y, float* rstd, void* stream);
+/* Its backward: dx (may be NULL) and dgamma[d] = sum over rows; scratch of kg_train_rmsnorm_bwd_scratch(rows, d) bytes
+ * holds per-block shares that are added in a fixed order.  d <= 8192. */
+size_t kg_train_rmsnorm_bwd_scratch(int rows, int d);
+int kg_train_rmsnorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* rstd, int rows, int d,
+                         void* dx, float* dgamma, void* scratch, void* stream);
+/* apply_rotary_pos_emb (kangaroo/adapter.py:87-95) in place on [rows][n_heads][head_dim], position = row % S,
+ * tables [S][head_dim/2] fp32; inverse != 0 applies the adjoint (backward pass). */
+int kg_train_rope(int dtype, void* x, long long rows, int S, int n_heads, int head_dim, const float* cos_t, const float* sin_t, int inverse, void* stream);
+/* Attention probabilities in place over the scores [B][H][S][S] (kangaroo/adapter.py:195-211): softmax(scale * s) over
+ * the keys j <= i with key_mask[b][j] != 0 (causal + padding masks of :38-67,327-348), zeros elsewhere.  S <= 4096. */
+int kg_train_softmax_fwd(int dtype, void* scores, const int* key_mask, int B, int H, int S, float scale, void* stream);
+/* dscores = scale * p * (dp - sum(dp * p)) written over dprobs. */
+int kg_train_softmax_bwd(int dtype, const void* probs, void* dprobs, int B, int H, int S, float scale, void* stream);
+/* train.py:265-279 for rows of out-logits and target-logits [rows][vocab]: row_loss = -sum_v softmax(t)_v log_softmax(o)_v,
+ * row_acc = sum_v min(softmax(t)_v, softmax(o)_v), and the gradient grad_scale * (softmax(o) - softmax(t)) written over
+ * logits_out; rows with loss_mask 0 get zeros. */
+int kg_train_softce(int dtype, void* logits_out, const void* logits_tgt, const int* loss_mask, int rows, int vocab, float grad_scale,
+                    float* row_loss, float* row_acc, void* stream);
+/* accelerator.clip_grad_value_(clip) + torch.optim.AdamW step `step` (1-based) on n fp32 parameters (train.py:227,285-286);
+ * grad_dtype 0 fp16, 1 bf16, 2 fp32, multiplied by inv_scale first; p16 (may be NULL) receives the 16-bit copy
+ * (copy_dtype) that the GEMMs read. */
+int kg_train_adamw(float* p, float* m, float* v, const void* grad, int grad_dtype, float inv_scale, float clip, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, long long n, void* p16, int copy_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

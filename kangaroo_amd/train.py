@@ -1,0 +1,269 @@
+"""Adapter training on MI355X: the loop body of the reference's train.py (:258-296) over the C ABI.
+
+The adapter is one attention-only decoder layer plus the final RMSNorm (kangaroo/adapter.py:317-460), trained so
+that the frozen lm_head on its output matches the head on the full model's last hidden state (soft-label cross
+entropy, train.py:265-278).  Per step and rank:
+
+    forward   RMSNorm -> q/k/v GEMMs -> RoPE -> scores GEMM -> masked softmax -> context GEMM -> o_proj GEMM
+              -> residual -> RMSNorm -> two lm_head GEMMs (adapter output, target)
+    loss      one fused pass over both logit rows: log-softmax, cross entropy, expected acceptance, dlogits
+    backward  the transposed GEMMs, softmax / RoPE / RMSNorm backward kernels
+    update    gradient all-reduce over the data-parallel group (RCCL), clip by value, AdamW, 16-bit weight copy
+
+The GEMMs run over batch x sequence rows (thousands): compute-bound library calls (`torch.matmul` = hipBLASLt).
+Everything between them is a hand-written kernel of libkangaroo_hip.so (csrc/train.hip).  With 288 GB of HBM the
+step materialises the attention probabilities [B, H, S, S] and both logit matrices [B*S, V] in 16 bit instead of
+recomputing them (4 x 2048 tokens at the 7B shape: 1 GiB + 2 x 0.5 GiB).
+
+Mixed precision as the reference runs it (accelerate, fp16 autocast, train.py:46): fp32 master weights and
+optimizer state, 16-bit activations and GEMM inputs, fp32 statistics; gradients of activations are carried in 16
+bit under a constant loss scale that the optimizer kernel divides out.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from .config import LlamaShape
+from .packing import rope_tables
+
+PARAM_KEYS = {
+    "input_layernorm": "layers.0.input_layernorm.weight",
+    "q_proj": "layers.0.self_attn.q_proj.weight",
+    "k_proj": "layers.0.self_attn.k_proj.weight",
+    "v_proj": "layers.0.self_attn.v_proj.weight",
+    "o_proj": "layers.0.self_attn.o_proj.weight",
+    "norm": "norm.weight",
+}
+
+
+def prepare_sample(data: Dict[str, torch.Tensor], exit_layer, max_len: int = 2048) -> Dict[str, torch.Tensor]:
+    """CustomDataset.__getitem__ (train.py:109-148) on one loaded sample: truncate to max_len, shift the early-exit
+    and final hidden states (and input ids) left by one with a zero row appended, clear the last loss_mask entry."""
+    hidden = data["hidden_state"][:max_len][None, :]
+    ids = data["input_ids"][:max_len][None, :]
+    loss_mask = data["loss_mask"][:max_len].tolist()
+    early = data[f"hidden_state_layer{exit_layer}"][:max_len][None, :]
+    length = hidden.shape[1]
+    loss_mask[-1] = 0
+    zrow = torch.zeros(1, 1, hidden.shape[2], dtype=hidden.dtype)
+    return {
+        "attention_mask": [1] * length,
+        "loss_mask": loss_mask,
+        "target": torch.cat((hidden[:, 1:, :], zrow), dim=1),
+        "hidden_state_big": hidden,
+        "input_ids": torch.cat((ids[:, 1:], torch.zeros(1, 1, dtype=ids.dtype)), dim=1),
+        "hidden_state_early": torch.cat((early[:, 1:, :], zrow.to(early.dtype)), dim=1),
+    }
+
+
+class DataCollatorWithPadding:
+    """train.py:151-185: right-pad every field with zeros to the longest sample of the batch."""
+
+    def __call__(self, features: Sequence[Dict]) -> Dict[str, torch.Tensor]:
+        n = max(f["hidden_state_big"].shape[1] for f in features)
+
+        def pad3(t):
+            return torch.cat((t, torch.zeros(t.shape[0], n - t.shape[1], t.shape[2], dtype=t.dtype)), dim=1)
+
+        def pad2(t):
+            return torch.cat((t, torch.zeros(t.shape[0], n - t.shape[1], dtype=t.dtype)), dim=1)
+
+        return {
+            "input_ids": torch.cat([pad2(f["input_ids"]) for f in features]),
+            "hidden_states": torch.cat([pad3(f["hidden_state_big"]) for f in features]),
+            "hidden_states_early": torch.cat([pad3(f["hidden_state_early"]) for f in features]),
+            "target": torch.cat([pad3(f["target"]) for f in features]),
+            "loss_mask": torch.tensor([f["loss_mask"] + [0] * (n - len(f["loss_mask"])) for f in features]),
+            "attention_mask": torch.tensor([f["attention_mask"] + [0] * (n - len(f["attention_mask"])) for f in features]),
+        }
+
+
+def linear_warmup_lr(base_lr: float, step: int, warmup: int, total: int) -> float:
+    """The factor transformers.get_linear_schedule_with_warmup gives optimizer step `step` (0-based), times
+    base_lr (train.py:235): the first step runs at 0."""
+    if step < warmup:
+        return base_lr * step / max(1, warmup)
+    return base_lr * max(0.0, (total - step) / max(1, total - warmup))
+
+
+class GradSync:
+    """Data-parallel gradient mean (what accelerate's DDP wrapper does for train.py:284): gradients are copied
+    into fp32 buckets as the backward pass produces them and each bucket's all-reduce is started at once, so the
+    exchange of the o_proj bucket overlaps the attention backward; `finish` waits and divides by the world size."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.pending = []
+
+    def start(self, tensors: List[torch.Tensor]) -> List[torch.Tensor]:
+        """tensors -> fp32 views of one flat bucket being reduced."""
+        flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+        work = self.dist.all_reduce(flat, group=self.group, async_op=True) if self.world > 1 else None
+        self.pending.append((flat, work))
+        out, off = [], 0
+        for t in tensors:
+            out.append(flat[off:off + t.numel()].view(t.shape))
+            off += t.numel()
+        return out
+
+    def finish(self) -> None:
+        for flat, work in self.pending:
+            if work is not None:
+                work.wait()
+                flat.div_(self.world)
+        self.pending = []
+
+
+class AdapterTrainer:
+    """One optimisation step per `step(batch)` call; `state_dict()` returns the adapter in the reference's key names
+    (loadable by KangarooModel / kangaroo/kangaroo_model.py:27-30)."""
+
+    def __init__(self, shape: LlamaShape, adapter_sd: Dict[str, torch.Tensor], head_weight: torch.Tensor, dtype=torch.float16,
+                 lr: float = 5e-5, betas=(0.9, 0.95), adam_eps: float = 1e-8, weight_decay: float = 1e-2, grad_clip: float = 0.5,
+                 num_warmup_steps: int = 2000, total_steps: int = 800000, loss_scale: Optional[float] = None, device="cuda", group=None):
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("dtype must be float16 or bfloat16")
+        if not torch.cuda.is_available():
+            raise _lib.KangarooHipError("adapter training needs a GPU: there is no CPU path (the CPU restatement lives in oracle/ for tests)")
+        self.lib = _lib.lib()
+        self.shape, self.dtype, self.device = shape, dtype, torch.device(device)
+        self.dt = _lib.DT_F16 if dtype == torch.float16 else _lib.DT_BF16
+        self.lr, self.betas, self.adam_eps, self.wd, self.clip = lr, betas, adam_eps, weight_decay, grad_clip
+        self.warmup, self.total = num_warmup_steps, total_steps
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (256.0 if dtype == torch.float16 else 1.0)
+        self.t = 0
+        self.sync = GradSync(group)
+        self.p = {k: adapter_sd[name].detach().to(self.device, torch.float32).contiguous().clone() for k, name in PARAM_KEYS.items()}
+        self.m = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.w16 = {k: v.to(dtype) for k, v in self.p.items() if v.dim() == 2}
+        self.head16 = head_weight.detach().to(self.device, dtype).contiguous()
+        cos, sin = rope_tables(shape.head_dim, shape.max_position_embeddings, shape.rope_base, device=self.device)
+        self.cos, self.sin = cos.contiguous(), sin.contiguous()
+
+    # -- kernel wrappers -------------------------------------------------------------
+    def _st(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _p(t: Optional[torch.Tensor]):
+        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+    def _rmsnorm_fwd(self, x, gamma):
+        rows, d = x.shape
+        y = torch.empty_like(x)
+        rstd = torch.empty(rows, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.kg_train_rmsnorm_fwd(self.dt, self._p(x), self._p(gamma), self.shape.rms_norm_eps, rows, d, self._p(y), self._p(rstd), self._st()), "kg_train_rmsnorm_fwd")
+        return y, rstd
+
+    def _rmsnorm_bwd(self, dy, x, gamma, rstd, want_dx: bool):
+        rows, d = x.shape
+        dx = torch.empty_like(x) if want_dx else None
+        dg = torch.empty(d, dtype=torch.float32, device=self.device)
+        scratch = torch.empty(self.lib.kg_train_rmsnorm_bwd_scratch(rows, d), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.kg_train_rmsnorm_bwd(self.dt, self._p(dy), self._p(x), self._p(gamma), self._p(rstd), rows, d, self._p(dx), self._p(dg), self._p(scratch), self._st()),
+                   "kg_train_rmsnorm_bwd")
+        return dx, dg
+
+    def _rope(self, x, rows, S, n_heads, inverse: bool):
+        _lib.check(self.lib.kg_train_rope(self.dt, self._p(x), rows, S, n_heads, self.shape.head_dim, self._p(self.cos), self._p(self.sin), 1 if inverse else 0, self._st()), "kg_train_rope")
+
+    # -- one step --------------------------------------------------------------------
+    def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, float]:
+        sh, dt, dev = self.shape, self.dtype, self.device
+        H, Hkv, hd, d, V = sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim, sh.hidden_size, sh.vocab_size
+        x3 = batch["hidden_states_early"].to(dev, dt)
+        B, S, _ = x3.shape
+        if S > sh.max_position_embeddings:
+            raise ValueError("sequence longer than max_position_embeddings")
+        R = B * S
+        x = x3.reshape(R, d).contiguous()
+        tgt = batch["target"].to(dev, dt).reshape(R, d).contiguous()
+        key_mask = batch["attention_mask"].to(dev, torch.int32).contiguous()
+        loss_mask = batch["loss_mask"].to(dev, torch.int32).reshape(R).contiguous()
+        n_loss = int(loss_mask.sum().item())
+        if n_loss == 0:
+            raise ValueError("the batch has no position with loss_mask == 1")
+        W = self.w16
+        scale = 1.0 / math.sqrt(hd)
+        rep = H // Hkv
+
+        # ---- forward (kangaroo/adapter.py:378-460) ----
+        xn, rstd1 = self._rmsnorm_fwd(x, self.p["input_layernorm"])
+        q = xn @ W["q_proj"].t()
+        k = xn @ W["k_proj"].t()
+        v = xn @ W["v_proj"].t()
+        self._rope(q, R, S, H, False)
+        self._rope(k, R, S, Hkv, False)
+        qh = q.view(B, S, H, hd).transpose(1, 2)
+        kh = k.view(B, S, Hkv, hd).transpose(1, 2)
+        vh = v.view(B, S, Hkv, hd).transpose(1, 2)
+        if rep > 1:
+            kh = kh.repeat_interleave(rep, dim=1)
+            vh = vh.repeat_interleave(rep, dim=1)
+        probs = torch.matmul(qh, kh.transpose(2, 3)).contiguous()                      # scores, then probabilities in place
+        _lib.check(self.lib.kg_train_softmax_fwd(self.dt, self._p(probs), self._p(key_mask), B, H, S, scale, self._st()), "kg_train_softmax_fwd")
+        ctx = torch.matmul(probs, vh).transpose(1, 2).reshape(R, H * hd)
+        h = x + ctx @ W["o_proj"].t()
+        hn, rstd2 = self._rmsnorm_fwd(h, self.p["norm"])
+
+        # ---- loss through the frozen head (train.py:265-279) ----
+        logits = hn @ self.head16.t()                                                # becomes dlogits
+        tlogits = tgt @ self.head16.t()
+        row_loss = torch.empty(R, dtype=torch.float32, device=dev)
+        row_acc = torch.empty(R, dtype=torch.float32, device=dev)
+        _lib.check(self.lib.kg_train_softce(self.dt, self._p(logits), self._p(tlogits), self._p(loss_mask), R, V, self.loss_scale / n_loss,
+                                            self._p(row_loss), self._p(row_acc), self._st()), "kg_train_softce")
+        del tlogits
+
+        # ---- backward ----
+        dhn = logits @ self.head16
+        del logits
+        dh, dg2 = self._rmsnorm_bwd(dhn, h, self.p["norm"], rstd2, True)
+        g_o = dh.t() @ ctx                                                           # [d, H*hd]
+        (g_o32, dg2s) = self.sync.start([g_o, dg2])
+        dctx = (dh @ W["o_proj"]).view(B, S, H, hd).transpose(1, 2)
+        dprobs = torch.matmul(dctx, vh.transpose(2, 3)).contiguous()
+        dvh = torch.matmul(probs.transpose(2, 3), dctx)                              # [B, H, S, hd]
+        _lib.check(self.lib.kg_train_softmax_bwd(self.dt, self._p(probs), self._p(dprobs), B, H, S, scale, self._st()), "kg_train_softmax_bwd")
+        dqh = torch.matmul(dprobs, kh)
+        dkh = torch.matmul(dprobs.transpose(2, 3), qh)
+        del probs, dprobs
+        if rep > 1:
+            dkh = dkh.view(B, Hkv, rep, S, hd).sum(dim=2)
+            dvh = dvh.view(B, Hkv, rep, S, hd).sum(dim=2)
+        dq = dqh.transpose(1, 2).reshape(R, H * hd).contiguous()
+        dk = dkh.transpose(1, 2).reshape(R, Hkv * hd).contiguous()
+        dv = dvh.transpose(1, 2).reshape(R, Hkv * hd).contiguous()
+        self._rope(dq, R, S, H, True)
+        self._rope(dk, R, S, Hkv, True)
+        g_q, g_k, g_v = dq.t() @ xn, dk.t() @ xn, dv.t() @ xn
+        dxn = dq @ W["q_proj"] + dk @ W["k_proj"] + dv @ W["v_proj"]
+        _, dg1 = self._rmsnorm_bwd(dxn, x, self.p["input_layernorm"], rstd1, False)
+        (g_q32, g_k32, g_v32, dg1s) = self.sync.start([g_q, g_k, g_v, dg1])
+        self.sync.finish()
+        grads = {"input_layernorm": dg1s, "q_proj": g_q32, "k_proj": g_k32, "v_proj": g_v32, "o_proj": g_o32, "norm": dg2s}
+
+        # ---- update (train.py:285-296) ----
+        lr = linear_warmup_lr(self.lr, self.t, self.warmup, self.total)
+        self.t += 1
+        for key, g in grads.items():
+            p16 = self.w16.get(key)
+            _lib.check(self.lib.kg_train_adamw(self._p(self.p[key]), self._p(self.m[key]), self._p(self.v[key]), self._p(g), 2, 1.0 / self.loss_scale, self.clip, lr,
+                                               self.betas[0], self.betas[1], self.adam_eps, self.wd, self.t, self.p[key].numel(), self._p(p16), self.dt, self._st()),
+                       "kg_train_adamw")
+        self.last_grads = {k: g / self.loss_scale for k, g in grads.items()}          # unscaled, before clipping (tests, logging)
+        loss = float(row_loss.sum().item()) / n_loss
+        acc = float(row_acc.sum().item()) / n_loss
+        return {"loss": loss, "prob_acc": acc, "lr": lr, "tokens": R, "loss_positions": n_loss}
+
+    def state_dict(self, dtype=None) -> Dict[str, torch.Tensor]:
+        return {PARAM_KEYS[k]: (v.to(dtype) if dtype is not None else v.clone()) for k, v in self.p.items()}
