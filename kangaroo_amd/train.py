@@ -132,7 +132,7 @@ class AdapterTrainer:
         if dtype not in (torch.float16, torch.bfloat16):
             raise ValueError("dtype must be float16 or bfloat16")
         if not torch.cuda.is_available():
-            raise _lib.KangarooHipError("adapter training needs a GPU: there is no CPU path (the CPU restatement lives in oracle/ for tests)")
+            raise _lib.KangarooHipError("adapter training needs a GPU: there is no CPU path")
         self.lib = _lib.lib()
         self.shape, self.dtype, self.device = shape, dtype, torch.device(device)
         self.dt = _lib.DT_F16 if dtype == torch.float16 else _lib.DT_BF16
