@@ -24,7 +24,7 @@ from kangaroo_amd.weights import Recipe, synth_state_dicts
 from oracle import kangaroo_oracle as ko
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "*.npz")) if not p.endswith("layers.npz"))
+CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "*.npz")) if not p.endswith("layers.npz") and not os.path.basename(p).startswith("train_"))
 LOGIT_TOL = 1e-2
 KG_STEPS_MAX = 7           # a round writes at most steps + 1 = 7 tokens
 

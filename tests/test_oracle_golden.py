@@ -13,7 +13,7 @@ import torch
 from oracle import kangaroo_oracle as ko
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "*.npz")) if not p.endswith("layers.npz"))
+CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "*.npz")) if not p.endswith("layers.npz") and not os.path.basename(p).startswith("train_"))
 
 
 def load_case(path):
