@@ -283,9 +283,10 @@ int kg_train_softmax_fwd(int dtype, void* scores, const int* key_mask, int B, in
 int kg_train_softmax_bwd(int dtype, const void* probs, void* dprobs, int B, int H, int S, float scale, void* stream);
 /* train.py:265-279 for rows of out-logits and target-logits [rows][vocab]: row_loss = -sum_v softmax(t)_v log_softmax(o)_v,
  * row_acc = sum_v min(softmax(t)_v, softmax(o)_v), and the gradient grad_scale * (softmax(o) - softmax(t)) written over
- * logits_out; rows with loss_mask 0 get zeros. */
+ * logits_out; rows with loss_mask 0 get zeros.  row_rank (may be NULL): how many out-logits lie above the out-logit of the
+ * target's argmax token, i.e. the target is among the top k predictions iff rank < k (train.py:298-305); -1 outside the mask. */
 int kg_train_softce(int dtype, void* logits_out, const void* logits_tgt, const int* loss_mask, int rows, int vocab, float grad_scale,
-                    float* row_loss, float* row_acc, void* stream);
+                    float* row_loss, float* row_acc, int* row_rank, void* stream);
 /* accelerator.clip_grad_value_(clip) + torch.optim.AdamW step `step` (1-based) on n fp32 parameters (train.py:227,285-286);
  * grad_dtype 0 fp16, 1 bf16, 2 fp32, multiplied by inv_scale first; p16 (may be NULL) receives the 16-bit copy
  * (copy_dtype) that the GEMMs read. */

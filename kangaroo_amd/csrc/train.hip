@@ -36,61 +36,119 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// A piece = W consecutive 16-bit values <-> floats.  W = 8: one 16-byte access (rows are 16-byte aligned when
+// the row length is a multiple of 8: the launchers pick W by that); W = 1: any row length.
+template <int DT, int W> __device__ __forceinline__ void loadw(const unsigned short* p, float (&f)[W]) {
+    if (W == 8) {
+        const kg_us8 v = __builtin_bit_cast(kg_us8, *(const kg_u4*)p);
+#pragma unroll
+        for (int e = 0; e < W; ++e) f[e] = KgT<DT>::to_f(v[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < W; ++e) f[e] = KgT<DT>::to_f(p[e]);
+    }
+}
+template <int DT, int W> __device__ __forceinline__ void storew(unsigned short* p, const float (&f)[W]) {
+    if (W == 8) {
+        kg_us8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = KgT<DT>::from_f(f[e % W]);
+        *(kg_u4*)p = __builtin_bit_cast(kg_u4, v);
+    } else {
+#pragma unroll
+        for (int e = 0; e < W; ++e) p[e] = KgT<DT>::from_f(f[e]);
+    }
+}
+
 // y = round16(gamma * x * rstd), rstd = rsqrt(mean(x^2) + eps) kept for the backward pass
-template <int DT>
+template <int DT, int W>
 __global__ void __launch_bounds__(TB) rmsnorm_fwd_kernel(const unsigned short* x, const float* gamma, float eps, int d, unsigned short* y, float* rstd_out) {
-    typedef KgT<DT> T;
     __shared__ float red[4];
     const size_t row = blockIdx.x;
     const unsigned short* xr = x + row * d;
+    constexpr int NP = 32 / W;                     // pieces per thread: d <= 8192
+    float v[NP][W];
     float ss = 0.f;
-    for (int i = threadIdx.x; i < d; i += TB) { const float f = T::to_f(xr[i]); ss += f * f; }
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        const int i0 = (threadIdx.x + c * TB) * W;
+        if (i0 < d) {
+            loadw<DT, W>(xr + i0, v[c]);
+#pragma unroll
+            for (int e = 0; e < W; ++e) ss += v[c][e] * v[c][e];
+        }
+    }
     ss = block_sum(ss, red);
     const float rstd = rsqrtf(ss / (float)d + eps);
     if (threadIdx.x == 0) rstd_out[row] = rstd;
-    for (int i = threadIdx.x; i < d; i += TB) y[row * d + i] = T::from_f(gamma[i] * (T::to_f(xr[i]) * rstd));
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        const int i0 = (threadIdx.x + c * TB) * W;
+        if (i0 < d) {
+            float o[W];
+#pragma unroll
+            for (int e = 0; e < W; ++e) o[e] = gamma[i0 + e] * (v[c][e] * rstd);
+            storew<DT, W>(y + row * d + i0, o);
+        }
+    }
 }
 
 // With g = gamma * dy and xh = x * rstd:  dx = rstd * (g - xh * mean(g * xh)),  dgamma = sum over rows of dy * xh.
 // Block b walks rows b, b + gridDim.x, ... and leaves its share of dgamma in part[b][d]; a second kernel adds the
 // shares in block order.
-template <int DT>
+template <int DT, int W>
 __global__ void __launch_bounds__(TB) rmsnorm_bwd_kernel(const unsigned short* dy, const unsigned short* x, const float* gamma, const float* rstd,
                                                           int rows, int d, unsigned short* dx, float* part) {
-    typedef KgT<DT> T;
     __shared__ float red[4];
-    constexpr int MAXC = 32;                       // columns per thread: d <= 8192
-    float dg[MAXC];
+    constexpr int NP = 32 / W;                     // pieces per thread: d <= 8192
+    float dg[NP][W], gm[NP][W];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) dg[c] = 0.f;
+    for (int c = 0; c < NP; ++c) {
+        const int i0 = (threadIdx.x + c * TB) * W;
+#pragma unroll
+        for (int e = 0; e < W; ++e) { dg[c][e] = 0.f; gm[c][e] = (i0 < d) ? gamma[i0 + e] : 0.f; }
+    }
     for (size_t row = blockIdx.x; row < (size_t)rows; row += gridDim.x) {
         const float rs = rstd[row];
+        float g[NP][W], xh[NP][W];
         float dot = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int i = threadIdx.x + c * TB;
-            if (i < d) {
-                const float g = gamma[i] * T::to_f(dy[row * d + i]), xh = T::to_f(x[row * d + i]) * rs;
-                dot += g * xh;
-                dg[c] += T::to_f(dy[row * d + i]) * xh;
+        for (int c = 0; c < NP; ++c) {
+            const int i0 = (threadIdx.x + c * TB) * W;
+            if (i0 < d) {
+                float dyv[W];
+                loadw<DT, W>(dy + row * d + i0, dyv);
+                loadw<DT, W>(x + row * d + i0, xh[c]);
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    xh[c][e] *= rs;
+                    g[c][e] = gm[c][e] * dyv[e];
+                    dot += g[c][e] * xh[c][e];
+                    dg[c][e] += dyv[e] * xh[c][e];
+                }
             }
         }
         dot = block_sum(dot, red) / (float)d;
         if (dx) {
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
-                const int i = threadIdx.x + c * TB;
-                if (i < d) {
-                    const float g = gamma[i] * T::to_f(dy[row * d + i]), xh = T::to_f(x[row * d + i]) * rs;
-                    dx[row * d + i] = T::from_f(rs * (g - xh * dot));
+            for (int c = 0; c < NP; ++c) {
+                const int i0 = (threadIdx.x + c * TB) * W;
+                if (i0 < d) {
+                    float o[W];
+#pragma unroll
+                    for (int e = 0; e < W; ++e) o[e] = rs * (g[c][e] - xh[c][e] * dot);
+                    storew<DT, W>(dx + row * d + i0, o);
                 }
             }
         }
     }
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        const int i = threadIdx.x + c * TB;
-        if (i < d) part[(size_t)blockIdx.x * d + i] = dg[c];
+    for (int c = 0; c < NP; ++c) {
+        const int i0 = (threadIdx.x + c * TB) * W;
+        if (i0 < d) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) part[(size_t)blockIdx.x * d + i0 + e] = dg[c][e];
+        }
     }
 }
 __global__ void column_sum_kernel(const float* part, int nblk, int d, float* out) {
@@ -121,99 +179,167 @@ __global__ void rope_kernel(unsigned short* x, size_t rows, int S, int n_heads, 
 
 // Row (b, h, i) of the scores [B][H][S][S]: p_j = softmax_j(scale * s_j) over the keys j <= i with
 // key_mask[b][j] != 0 (the causal mask plus the padding mask of kangaroo/adapter.py:327-348), zeros elsewhere.
-template <int DT>
+// Thread t owns the pieces t, t + 256, ... (S <= 4096); pieces wholly in the future are never read.
+template <int DT, int W>
 __global__ void __launch_bounds__(TB) softmax_fwd_kernel(unsigned short* s, const int* key_mask, int H, int S, float scale) {
-    typedef KgT<DT> T;
     __shared__ float red[4];
     const size_t row = blockIdx.x;
     const int i = (int)(row % S), b = (int)(row / ((size_t)H * S));
     unsigned short* sr = s + row * S;
     const int* km = key_mask + (size_t)b * S;
-    constexpr int MAXC = 16;                       // S <= 4096
-    float v[MAXC];
+    constexpr int NP = 16 / W;
+    float v[NP][W];
     float mx = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        const int j = threadIdx.x + c * TB;
-        const bool ok = j <= i && j < S && km[j] != 0;
-        v[c] = ok ? T::to_f(sr[j]) * scale : -INFINITY;
-        mx = fmaxf(mx, v[c]);
+    for (int c = 0; c < NP; ++c) {
+        const int j0 = (threadIdx.x + c * TB) * W;
+#pragma unroll
+        for (int e = 0; e < W; ++e) v[c][e] = -INFINITY;
+        if (j0 <= i && j0 < S) {
+            float f[W];
+            loadw<DT, W>(sr + j0, f);
+            int kmv[W];
+            if (W == 8) {       // the mask row is 32-byte aligned when S is a multiple of 8
+                const kg_u4 a = *(const kg_u4*)(km + j0), b4 = *(const kg_u4*)(km + j0 + 4);
+                kmv[0] = a.x; kmv[1 % W] = a.y; kmv[2 % W] = a.z; kmv[3 % W] = a.w; kmv[4 % W] = b4.x; kmv[5 % W] = b4.y; kmv[6 % W] = b4.z; kmv[7 % W] = b4.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e) kmv[e] = km[j0 + e];
+            }
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const bool ok = j0 + e <= i && kmv[e] != 0;
+                v[c][e] = ok ? f[e] * scale : -INFINITY;
+                mx = fmaxf(mx, v[c][e]);
+            }
+        }
     }
     mx = block_max(mx, red);
     float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) { v[c] = (v[c] == -INFINITY) ? 0.f : __expf(v[c] - mx); sum += v[c]; }
+    for (int c = 0; c < NP; ++c)
+#pragma unroll
+        for (int e = 0; e < W; ++e) { v[c][e] = (v[c][e] == -INFINITY) ? 0.f : __expf(v[c][e] - mx); sum += v[c][e]; }
     sum = block_sum(sum, red);
     const float inv = sum > 0.f ? 1.f / sum : 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        const int j = threadIdx.x + c * TB;
-        if (j < S) sr[j] = T::from_f(v[c] * inv);
+    for (int c = 0; c < NP; ++c) {
+        const int j0 = (threadIdx.x + c * TB) * W;
+        if (j0 < S) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) v[c][e] *= inv;
+            storew<DT, W>(sr + j0, v[c]);
+        }
     }
 }
-// ds_j = scale * p_j * (dp_j - sum_k dp_k p_k), written over dp
-template <int DT>
+// ds_j = scale * p_j * (dp_j - sum_k dp_k p_k), written over dp; p is zero beyond the query's position, so those
+// pieces are written as zeros without being read
+template <int DT, int W>
 __global__ void __launch_bounds__(TB) softmax_bwd_kernel(const unsigned short* p, unsigned short* dp, int S, float scale) {
-    typedef KgT<DT> T;
     __shared__ float red[4];
     const size_t row = blockIdx.x;
+    const int i = (int)(row % S);
     const unsigned short* pr = p + row * S;
     unsigned short* dr = dp + row * S;
-    constexpr int MAXC = 16;
-    float pv[MAXC], dv[MAXC];
+    constexpr int NP = 16 / W;
+    float pv[NP][W], dv[NP][W];
     float dot = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        const int j = threadIdx.x + c * TB;
-        pv[c] = j < S ? T::to_f(pr[j]) : 0.f;
-        dv[c] = j < S ? T::to_f(dr[j]) : 0.f;
-        dot += pv[c] * dv[c];
+    for (int c = 0; c < NP; ++c) {
+        const int j0 = (threadIdx.x + c * TB) * W;
+        if (j0 <= i && j0 < S) {
+            loadw<DT, W>(pr + j0, pv[c]);
+            loadw<DT, W>(dr + j0, dv[c]);
+#pragma unroll
+            for (int e = 0; e < W; ++e) dot += pv[c][e] * dv[c][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < W; ++e) { pv[c][e] = 0.f; dv[c][e] = 0.f; }
+        }
     }
     dot = block_sum(dot, red);
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        const int j = threadIdx.x + c * TB;
-        if (j < S) dr[j] = T::from_f(scale * pv[c] * (dv[c] - dot));
+    for (int c = 0; c < NP; ++c) {
+        const int j0 = (threadIdx.x + c * TB) * W;
+        if (j0 < S) {
+            float o[W];
+#pragma unroll
+            for (int e = 0; e < W; ++e) o[e] = scale * pv[c][e] * (dv[c][e] - dot);
+            storew<DT, W>(dr + j0, o);
+        }
     }
 }
 
 // One row of out-logits o and target-logits t (train.py:265-279):
 //   loss = lse(o) - sum_v softmax(t)_v o_v,   acc = sum_v min(softmax(t)_v, softmax(o)_v),
-//   dlogits_v = grad_scale * (softmax(o)_v - softmax(t)_v)   (written over o; zeros when the row's loss_mask is 0).
-template <int DT>
+//   dlogits_v = grad_scale * (softmax(o)_v - softmax(t)_v)   (written over o; zeros when the row's loss_mask is 0),
+//   rank = number of out-logits above the out-logit of the target's argmax (lowest index on ties): the target token is
+//   among the top k predictions iff rank < k (train.py:298-305); -1 for rows outside the loss mask.
+template <int DT, int W>
 __global__ void __launch_bounds__(TB) softce_kernel(unsigned short* o, const unsigned short* t, const int* loss_mask, int V, float grad_scale,
-                                                     float* row_loss, float* row_acc) {
+                                                     float* row_loss, float* row_acc, int* row_rank) {
     typedef KgT<DT> T;
     __shared__ float red[4];
     const size_t row = blockIdx.x;
     unsigned short* orow = o + row * V;
     const unsigned short* trow = t + row * V;
     if (loss_mask[row] == 0) {
-        for (int i = threadIdx.x; i < V; i += TB) orow[i] = 0;
-        if (threadIdx.x == 0) { row_loss[row] = 0.f; row_acc[row] = 0.f; }
+        const float z[W] = {};
+        for (int c = threadIdx.x; c < V / W; c += TB) storew<DT, W>(orow + W * c, z);
+        if (threadIdx.x == 0) { row_loss[row] = 0.f; row_acc[row] = 0.f; if (row_rank) row_rank[row] = -1; }
         return;
     }
+    // thread t takes pieces t, t + 256, ...; the row pair (4 * V bytes) stays in L2 between the sweeps
+    const int NPC = V / W;
     float mo = -INFINITY, mt = -INFINITY;
-    for (int i = threadIdx.x; i < V; i += TB) { mo = fmaxf(mo, T::to_f(orow[i])); mt = fmaxf(mt, T::to_f(trow[i])); }
+    for (int c = threadIdx.x; c < NPC; c += TB) {
+        float fo[W], ft[W];
+        loadw<DT, W>(orow + W * c, fo); loadw<DT, W>(trow + W * c, ft);
+#pragma unroll
+        for (int e = 0; e < W; ++e) { mo = fmaxf(mo, fo[e]); mt = fmaxf(mt, ft[e]); }
+    }
     mo = block_max(mo, red);
     mt = block_max(mt, red);
+    float o_at_target = 0.f;
+    if (row_rank) {
+        // lowest index holding the target's maximum, then its out-logit (block-uniform after the reductions)
+        int it = 0x7fffffff;
+        for (int c = threadIdx.x; c < NPC && it == 0x7fffffff; c += TB) {
+            float ft[W];
+            loadw<DT, W>(trow + W * c, ft);
+#pragma unroll
+            for (int e = W - 1; e >= 0; --e) if (ft[e] == mt) it = W * c + e;
+        }
+        it = -(int)block_max(-(float)it, red);          // indices < 2^24: exact in fp32
+        o_at_target = T::to_f(orow[it]);
+    }
     float so = 0.f, st = 0.f, cr = 0.f;
-    for (int i = threadIdx.x; i < V; i += TB) {
-        const float ov = T::to_f(orow[i]), et = expf(T::to_f(trow[i]) - mt);
-        so += expf(ov - mo); st += et; cr += et * ov;
+    for (int c = threadIdx.x; c < NPC; c += TB) {
+        float fo[W], ft[W];
+        loadw<DT, W>(orow + W * c, fo); loadw<DT, W>(trow + W * c, ft);
+#pragma unroll
+        for (int e = 0; e < W; ++e) { const float et = expf(ft[e] - mt); so += expf(fo[e] - mo); st += et; cr += et * fo[e]; }
     }
     so = block_sum(so, red);
     st = block_sum(st, red);
     cr = block_sum(cr, red);
     const float lse_o = mo + logf(so), inv_st = 1.f / st;
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < V; i += TB) {
-        const float po = expf(T::to_f(orow[i]) - lse_o), pt = expf(T::to_f(trow[i]) - mt) * inv_st;
-        acc += fminf(po, pt);
-        orow[i] = T::from_f(grad_scale * (po - pt));
+    float acc = 0.f, above = 0.f;
+    for (int c = threadIdx.x; c < NPC; c += TB) {
+        float fo[W], ft[W], g[W];
+        loadw<DT, W>(orow + W * c, fo); loadw<DT, W>(trow + W * c, ft);
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            const float po = expf(fo[e] - lse_o), pt = expf(ft[e] - mt) * inv_st;
+            acc += fminf(po, pt);
+            above += (fo[e] > o_at_target) ? 1.f : 0.f;
+            g[e] = grad_scale * (po - pt);
+        }
+        storew<DT, W>(orow + W * c, g);
     }
     acc = block_sum(acc, red);
-    if (threadIdx.x == 0) { row_loss[row] = lse_o - cr * inv_st; row_acc[row] = acc; }
+    above = block_sum(above, red);
+    if (threadIdx.x == 0) { row_loss[row] = lse_o - cr * inv_st; row_acc[row] = acc; if (row_rank) row_rank[row] = (int)above; }
 }
 
 // torch.optim.AdamW step t on one parameter, after clamping the unscaled gradient to [-clip, clip]
@@ -243,10 +369,13 @@ int done(const char* what) {
 }  // namespace
 
 extern "C" int kg_train_rmsnorm_fwd(int dtype, const void* x, const float* gamma, float eps, int rows, int d, void* y, float* rstd, void* stream) {
-    if (!x || !gamma || !y || !rstd || rows < 1 || d < 1) return -1;
+    if (!x || !gamma || !y || !rstd || rows < 1 || d < 1 || d > 32 * TB) return -1;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == KG_F16) hipLaunchKernelGGL(rmsnorm_fwd_kernel<KG_F16>, dim3(rows), dim3(TB), 0, st, (const unsigned short*)x, gamma, eps, d, (unsigned short*)y, rstd);
-    else hipLaunchKernelGGL(rmsnorm_fwd_kernel<KG_BF16>, dim3(rows), dim3(TB), 0, st, (const unsigned short*)x, gamma, eps, d, (unsigned short*)y, rstd);
+    const bool wide = (d & 7) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+#define KG_RF(D, W) hipLaunchKernelGGL((rmsnorm_fwd_kernel<D, W>), dim3(rows), dim3(TB), 0, st, (const unsigned short*)x, gamma, eps, d, (unsigned short*)y, rstd)
+    if (dtype == KG_F16) { if (wide) KG_RF(KG_F16, 8); else KG_RF(KG_F16, 1); }
+    else { if (wide) KG_RF(KG_BF16, 8); else KG_RF(KG_BF16, 1); }
+#undef KG_RF
     return done("kg_train_rmsnorm_fwd");
 }
 
@@ -257,8 +386,11 @@ extern "C" int kg_train_rmsnorm_bwd(int dtype, const void* dy, const void* x, co
     if (!dy || !x || !gamma || !rstd || !dgamma || !scratch || rows < 1 || d < 1 || d > 32 * TB) return -1;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = rows < 256 ? rows : 256;
-    if (dtype == KG_F16) hipLaunchKernelGGL(rmsnorm_bwd_kernel<KG_F16>, dim3(nblk), dim3(TB), 0, st, (const unsigned short*)dy, (const unsigned short*)x, gamma, rstd, rows, d, (unsigned short*)dx, (float*)scratch);
-    else hipLaunchKernelGGL(rmsnorm_bwd_kernel<KG_BF16>, dim3(nblk), dim3(TB), 0, st, (const unsigned short*)dy, (const unsigned short*)x, gamma, rstd, rows, d, (unsigned short*)dx, (float*)scratch);
+    const bool wide = (d & 7) == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
+#define KG_RB(D, W) hipLaunchKernelGGL((rmsnorm_bwd_kernel<D, W>), dim3(nblk), dim3(TB), 0, st, (const unsigned short*)dy, (const unsigned short*)x, gamma, rstd, rows, d, (unsigned short*)dx, (float*)scratch)
+    if (dtype == KG_F16) { if (wide) KG_RB(KG_F16, 8); else KG_RB(KG_F16, 1); }
+    else { if (wide) KG_RB(KG_BF16, 8); else KG_RB(KG_BF16, 1); }
+#undef KG_RB
     hipLaunchKernelGGL(column_sum_kernel, dim3((d + 255) / 256), dim3(256), 0, st, (const float*)scratch, nblk, d, dgamma);
     return done("kg_train_rmsnorm_bwd");
 }
@@ -277,8 +409,11 @@ extern "C" int kg_train_softmax_fwd(int dtype, void* scores, const int* key_mask
     if (!scores || !key_mask || B < 1 || H < 1 || S < 1 || S > 16 * TB) return -1;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((size_t)B * H * S));
-    if (dtype == KG_F16) hipLaunchKernelGGL(softmax_fwd_kernel<KG_F16>, grid, dim3(TB), 0, st, (unsigned short*)scores, key_mask, H, S, scale);
-    else hipLaunchKernelGGL(softmax_fwd_kernel<KG_BF16>, grid, dim3(TB), 0, st, (unsigned short*)scores, key_mask, H, S, scale);
+    const bool wide = (S & 7) == 0 && (((uintptr_t)scores | (uintptr_t)key_mask) & 15) == 0;
+    if (dtype == KG_F16) { if (wide) hipLaunchKernelGGL((softmax_fwd_kernel<KG_F16, 8>), grid, dim3(TB), 0, st, (unsigned short*)scores, key_mask, H, S, scale);
+                           else hipLaunchKernelGGL((softmax_fwd_kernel<KG_F16, 1>), grid, dim3(TB), 0, st, (unsigned short*)scores, key_mask, H, S, scale); }
+    else { if (wide) hipLaunchKernelGGL((softmax_fwd_kernel<KG_BF16, 8>), grid, dim3(TB), 0, st, (unsigned short*)scores, key_mask, H, S, scale);
+           else hipLaunchKernelGGL((softmax_fwd_kernel<KG_BF16, 1>), grid, dim3(TB), 0, st, (unsigned short*)scores, key_mask, H, S, scale); }
     return done("kg_train_softmax_fwd");
 }
 
@@ -286,17 +421,23 @@ extern "C" int kg_train_softmax_bwd(int dtype, const void* probs, void* dprobs, 
     if (!probs || !dprobs || B < 1 || H < 1 || S < 1 || S > 16 * TB) return -1;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((size_t)B * H * S));
-    if (dtype == KG_F16) hipLaunchKernelGGL(softmax_bwd_kernel<KG_F16>, grid, dim3(TB), 0, st, (const unsigned short*)probs, (unsigned short*)dprobs, S, scale);
-    else hipLaunchKernelGGL(softmax_bwd_kernel<KG_BF16>, grid, dim3(TB), 0, st, (const unsigned short*)probs, (unsigned short*)dprobs, S, scale);
+    const bool wide = (S & 7) == 0 && (((uintptr_t)probs | (uintptr_t)dprobs) & 15) == 0;
+    if (dtype == KG_F16) { if (wide) hipLaunchKernelGGL((softmax_bwd_kernel<KG_F16, 8>), grid, dim3(TB), 0, st, (const unsigned short*)probs, (unsigned short*)dprobs, S, scale);
+                           else hipLaunchKernelGGL((softmax_bwd_kernel<KG_F16, 1>), grid, dim3(TB), 0, st, (const unsigned short*)probs, (unsigned short*)dprobs, S, scale); }
+    else { if (wide) hipLaunchKernelGGL((softmax_bwd_kernel<KG_BF16, 8>), grid, dim3(TB), 0, st, (const unsigned short*)probs, (unsigned short*)dprobs, S, scale);
+           else hipLaunchKernelGGL((softmax_bwd_kernel<KG_BF16, 1>), grid, dim3(TB), 0, st, (const unsigned short*)probs, (unsigned short*)dprobs, S, scale); }
     return done("kg_train_softmax_bwd");
 }
 
 extern "C" int kg_train_softce(int dtype, void* logits_out, const void* logits_tgt, const int* loss_mask, int rows, int vocab, float grad_scale,
-                               float* row_loss, float* row_acc, void* stream) {
-    if (!logits_out || !logits_tgt || !loss_mask || !row_loss || !row_acc || rows < 1 || vocab < 1) return -1;
+                               float* row_loss, float* row_acc, int* row_rank, void* stream) {
+    if (!logits_out || !logits_tgt || !loss_mask || !row_loss || !row_acc || rows < 1 || vocab < 1 || vocab >= (1 << 24)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == KG_F16) hipLaunchKernelGGL(softce_kernel<KG_F16>, dim3(rows), dim3(TB), 0, st, (unsigned short*)logits_out, (const unsigned short*)logits_tgt, loss_mask, vocab, grad_scale, row_loss, row_acc);
-    else hipLaunchKernelGGL(softce_kernel<KG_BF16>, dim3(rows), dim3(TB), 0, st, (unsigned short*)logits_out, (const unsigned short*)logits_tgt, loss_mask, vocab, grad_scale, row_loss, row_acc);
+    const bool wide = (vocab & 7) == 0 && (((uintptr_t)logits_out | (uintptr_t)logits_tgt) & 15) == 0;
+#define KG_SOFTCE(D, W) hipLaunchKernelGGL((softce_kernel<D, W>), dim3(rows), dim3(TB), 0, st, (unsigned short*)logits_out, (const unsigned short*)logits_tgt, loss_mask, vocab, grad_scale, row_loss, row_acc, row_rank)
+    if (dtype == KG_F16) { if (wide) KG_SOFTCE(KG_F16, 8); else KG_SOFTCE(KG_F16, 1); }
+    else { if (wide) KG_SOFTCE(KG_BF16, 8); else KG_SOFTCE(KG_BF16, 1); }
+#undef KG_SOFTCE
     return done("kg_train_softce");
 }
 

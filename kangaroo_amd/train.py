@@ -220,8 +220,9 @@ class AdapterTrainer:
         tlogits = tgt @ self.head16.t()
         row_loss = torch.empty(R, dtype=torch.float32, device=dev)
         row_acc = torch.empty(R, dtype=torch.float32, device=dev)
+        row_rank = torch.empty(R, dtype=torch.int32, device=dev)
         _lib.check(self.lib.kg_train_softce(self.dt, self._p(logits), self._p(tlogits), self._p(loss_mask), R, V, self.loss_scale / n_loss,
-                                            self._p(row_loss), self._p(row_acc), self._st()), "kg_train_softce")
+                                            self._p(row_loss), self._p(row_acc), self._p(row_rank), self._st()), "kg_train_softce")
         del tlogits
 
         # ---- backward ----
@@ -261,9 +262,99 @@ class AdapterTrainer:
                                                self.betas[0], self.betas[1], self.adam_eps, self.wd, self.t, self.p[key].numel(), self._p(p16), self.dt, self._st()),
                        "kg_train_adamw")
         self.last_grads = {k: g / self.loss_scale for k, g in grads.items()}          # unscaled, before clipping (tests, logging)
-        loss = float(row_loss.sum().item()) / n_loss
-        acc = float(row_acc.sum().item()) / n_loss
-        return {"loss": loss, "prob_acc": acc, "lr": lr, "tokens": R, "loss_positions": n_loss}
+        sums = torch.stack([row_loss.sum(), row_acc.sum()] + [((row_rank >= 0) & (row_rank < k)).sum().float() for k in (1, 2, 3)]).tolist()
+        # top-k counts as train.py:298-309 accumulates them (the target token = argmax of the target head)
+        return {"loss": sums[0] / n_loss, "prob_acc": sums[1] / n_loss, "lr": lr, "tokens": R, "loss_positions": n_loss,
+                "top1_correct": int(sums[2]), "top2_correct": int(sums[3]), "top3_correct": int(sums[4])}
 
     def state_dict(self, dtype=None) -> Dict[str, torch.Tensor]:
         return {PARAM_KEYS[k]: (v.to(dtype) if dtype is not None else v.clone()) for k, v in self.p.items()}
+
+    def save_state(self, path: str) -> None:
+        """Everything a later call needs to continue (the role of accelerator.save_state, train.py:335): weights,
+        both AdamW moments and the step count, as one torch.save file of plain tensors."""
+        torch.save({"step": self.t, "p": {k: v.cpu() for k, v in self.p.items()}, "m": {k: v.cpu() for k, v in self.m.items()},
+                    "v": {k: v.cpu() for k, v in self.v.items()}}, path)
+
+    def load_state(self, path: str) -> None:
+        """accelerator.load_state (train.py:245-246) for a file written by save_state."""
+        st = torch.load(path, map_location="cpu", weights_only=True)
+        self.t = int(st["step"])
+        for k in self.p:
+            self.p[k].copy_(st["p"][k]); self.m[k].copy_(st["m"][k]); self.v[k].copy_(st["v"][k])
+            if k in self.w16:
+                self.w16[k].copy_(self.p[k])
+
+
+def list_files(path: str) -> List[str]:
+    """train.py:92-98."""
+    import os
+    out = []
+    for root, _, files in os.walk(path):
+        out += [os.path.join(root, f) for f in files]
+    return out
+
+
+def train_epoch(trainer: AdapterTrainer, files: Sequence[str], exit_layer, bs: int, max_len: int = 2048, seed: int = 0,
+                rank: int = 0, world: int = 1, log_steps: int = 20, log=print) -> Dict[str, float]:
+    """One epoch of train.py:250-333 over hidden-state files written by the reference's data generation
+    (each a torch.save of hidden_state / hidden_state_layer<L> / input_ids / loss_mask): shuffled batches of `bs`
+    files, every rank taking its own share of each epoch's order (DataLoader(shuffle=True) + accelerate's
+    sharding), the running totals the reference prints at the end of the epoch."""
+    g = torch.Generator().manual_seed(seed)
+    order = torch.randperm(len(files), generator=g).tolist()[rank::world]
+    collate = DataCollatorWithPadding()
+    tot = {"loss": 0.0, "batches": 0, "positions": 0, "top1": 0, "top2": 0, "top3": 0}
+    for b0 in range(0, len(order) - bs + 1, bs):
+        feats = [prepare_sample(torch.load(files[i], map_location="cpu", weights_only=True), exit_layer, max_len) for i in order[b0:b0 + bs]]
+        out = trainer.step(collate(feats))
+        tot["loss"] += out["loss"]; tot["batches"] += 1; tot["positions"] += out["loss_positions"]
+        for k in (1, 2, 3):
+            tot[f"top{k}"] += out[f"top{k}_correct"]
+        if rank == 0 and tot["batches"] % log_steps == 1:
+            log(f"Step: {tot['batches'] - 1}\tLR: {out['lr']}\tAccept: {out['prob_acc']}\tLoss: {out['loss']}")
+    n = max(1, tot["positions"])
+    return {"loss": tot["loss"] / max(1, tot["batches"]), "accuracy": tot["top1"] / n, "top2": tot["top2"] / n, "top3": tot["top3"] / n, "batches": tot["batches"]}
+
+
+def main(argv=None) -> None:
+    """The command line of train.py (:2-13) for one epoch (`--start` = epoch index, as start_train.py:29-41 calls it
+    once per epoch); run under torchrun for one process per GPU."""
+    import argparse, json, os
+    from .weights import load_base_state_dict
+    ap = argparse.ArgumentParser(description="adapter training, one epoch")
+    ap.add_argument("--basepath", required=True); ap.add_argument("--configpath", required=True)
+    ap.add_argument("--lr", type=float, default=3e-5); ap.add_argument("--bs", type=int, default=4); ap.add_argument("--exit_layer", default="2")
+    ap.add_argument("--tmpdir", required=True, help="directory of hidden-state files"); ap.add_argument("--cpdir", required=True); ap.add_argument("--start", type=int, default=0)
+    ap.add_argument("--dtype", default="float16")
+    a = ap.parse_args(argv)
+    world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")
+    shape = LlamaShape.from_hf_config(a.configpath)
+    head = load_base_state_dict(a.basepath, only=("lm_head.weight",))["lm_head.weight"]
+    os.makedirs(a.cpdir, exist_ok=True)
+    prev = os.path.join(a.cpdir, f"state_{a.start - 1}.pt")
+    g = torch.Generator().manual_seed(0)
+    d = shape.hidden_size
+    init = {PARAM_KEYS["q_proj"]: torch.nn.init.kaiming_uniform_(torch.empty(shape.q_dim, d), a=5 ** 0.5, generator=g),
+            PARAM_KEYS["k_proj"]: torch.nn.init.kaiming_uniform_(torch.empty(shape.kv_dim, d), a=5 ** 0.5, generator=g),
+            PARAM_KEYS["v_proj"]: torch.nn.init.kaiming_uniform_(torch.empty(shape.kv_dim, d), a=5 ** 0.5, generator=g),
+            PARAM_KEYS["o_proj"]: torch.nn.init.kaiming_uniform_(torch.empty(d, shape.q_dim), a=5 ** 0.5, generator=g),
+            PARAM_KEYS["input_layernorm"]: torch.ones(d), PARAM_KEYS["norm"]: torch.ones(d)}       # nn.Linear / LlamaRMSNorm defaults
+    tr = AdapterTrainer(shape, init, head, dtype=getattr(torch, a.dtype), lr=a.lr, num_warmup_steps=2000, total_steps=800000)
+    if a.start > 0:
+        tr.load_state(prev)
+    files = sorted(list_files(a.tmpdir))
+    files = files[:int(len(files) * 0.95)]                 # train.py:207
+    res = train_epoch(tr, files, a.exit_layer, a.bs, seed=a.start, rank=rank, world=world)
+    if rank == 0:
+        print(json.dumps({"epoch": a.start, **res}))
+        tr.save_state(os.path.join(a.cpdir, f"state_{a.start}.pt"))
+        torch.save(tr.state_dict(torch.float16), os.path.join(a.cpdir, "pytorch_model.bin"))
+
+
+if __name__ == "__main__":
+    main()

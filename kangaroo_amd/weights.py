@@ -107,22 +107,23 @@ def _torch_load(path: str):
     return torch.load(path, map_location="cpu", weights_only=True)
 
 
-def load_base_state_dict(model_dir: str) -> Dict[str, torch.Tensor]:
+def load_base_state_dict(model_dir: str, only=None) -> Dict[str, torch.Tensor]:
     """HF sharded checkpoint: pytorch_model.bin.index.json -> shard files, or a single
-    pytorch_model.bin, or safetensors equivalents."""
+    pytorch_model.bin, or safetensors equivalents.  only = names to keep: with an index file just the
+    shards that hold them are read (train.py:69-86 fetches lm_head.weight this way)."""
     idx = os.path.join(model_dir, "pytorch_model.bin.index.json")
     sidx = os.path.join(model_dir, "model.safetensors.index.json")
     out: Dict[str, torch.Tensor] = {}
     if os.path.exists(idx):
         with open(idx, "r") as f:
             wm = json.load(f)["weight_map"]
-        for shard in sorted(set(wm.values())):
+        for shard in sorted(set(wm.values()) if only is None else set(wm[k] for k in only)):
             out.update(_torch_load(os.path.join(model_dir, shard)))
     elif os.path.exists(sidx):
         from safetensors.torch import load_file
         with open(sidx, "r") as f:
             wm = json.load(f)["weight_map"]
-        for shard in sorted(set(wm.values())):
+        for shard in sorted(set(wm.values()) if only is None else set(wm[k] for k in only)):
             out.update(load_file(os.path.join(model_dir, shard)))
     elif os.path.exists(os.path.join(model_dir, "pytorch_model.bin")):
         out = _torch_load(os.path.join(model_dir, "pytorch_model.bin"))
@@ -131,6 +132,8 @@ def load_base_state_dict(model_dir: str) -> Dict[str, torch.Tensor]:
         out = load_file(os.path.join(model_dir, "model.safetensors"))
     else:
         raise FileNotFoundError(f"no checkpoint found under {model_dir}")
+    if only is not None:
+        out = {k: out[k] for k in only}
     return out
 
 

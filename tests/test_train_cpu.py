@@ -93,3 +93,19 @@ def test_gradient_mean_over_two_gloo_ranks():
     # every rank holds the same bits, so the replicas' weights stay identical step after step
     for i in range(3):
         assert torch.equal(out[0][i], out[1][i])
+
+
+def test_head_weight_alone_is_read_from_its_shard(tmp_path):
+    # train.py:69-86 opens only the shard that holds lm_head.weight
+    import json
+    a = {"model.embed_tokens.weight": torch.randn(5, 4)}
+    b = {"lm_head.weight": torch.randn(5, 4), "model.norm.weight": torch.ones(4)}
+    torch.save(a, tmp_path / "pytorch_model-00001-of-00002.bin")
+    torch.save(b, tmp_path / "pytorch_model-00002-of-00002.bin")
+    wm = {k: "pytorch_model-00001-of-00002.bin" for k in a}
+    wm.update({k: "pytorch_model-00002-of-00002.bin" for k in b})
+    (tmp_path / "pytorch_model.bin.index.json").write_text(json.dumps({"weight_map": wm}))
+    (tmp_path / "pytorch_model-00001-of-00002.bin").write_bytes(b"not a checkpoint")      # must not be opened
+    from kangaroo_amd.weights import load_base_state_dict
+    got = load_base_state_dict(str(tmp_path), only=("lm_head.weight",))
+    assert list(got) == ["lm_head.weight"] and torch.equal(got["lm_head.weight"], b["lm_head.weight"])

@@ -123,7 +123,13 @@ def test_soft_label_cross_entropy(dtype, code, rows, V):
     gs = 64.0 / n
     d = o.clone()
     rl = torch.empty(rows, dtype=torch.float32, device=DEV); ra = torch.empty_like(rl)
-    _lib.check(lib.kg_train_softce(code, vp(d), vp(t), vp(lm), rows, V, gs, vp(rl), vp(ra), st()), "softce")
+    rk = torch.empty(rows, dtype=torch.int32, device=DEV)
+    _lib.check(lib.kg_train_softce(code, vp(d), vp(t), vp(lm), rows, V, gs, vp(rl), vp(ra), vp(rk), st()), "softce")
+    # rank of the target's argmax token among the out-logits (train.py:298-305 counts rank < k)
+    tgt_tok = t.float().argmax(-1)
+    want_rank = (o.float() > o.float().gather(1, tgt_tok[:, None])).sum(-1).to(torch.int32)
+    want_rank = torch.where(lm != 0, want_rank, torch.full_like(want_rank, -1))
+    assert torch.equal(rk, want_rank)
     of = o.float().requires_grad_(True)
     tp = torch.softmax(t.float(), -1)
     lp = torch.log_softmax(of, -1)
@@ -256,3 +262,36 @@ def test_step_is_reproducible_bit_for_bit():
         outs.append({k: v.clone() for k, v in tr.state_dict().items()})
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_epoch_over_hidden_state_files_and_resume(tmp_path):
+    """train_epoch reads files shaped like the reference's data generation output (train.py:109-117), and a run
+    that saves its state after one epoch and reloads it continues exactly like a run that never stopped."""
+    from kangaroo_amd.train import AdapterTrainer, PARAM_KEYS, train_epoch
+    d, H, Hkv, V = 64, 4, 2, 97
+    shape = LlamaShape(hidden_size=d, num_hidden_layers=1, num_attention_heads=H, num_key_value_heads=Hkv, intermediate_size=2 * d,
+                       vocab_size=V, rms_norm_eps=1e-6, max_position_embeddings=64)
+    g = torch.Generator().manual_seed(4)
+    files = []
+    for i in range(8):
+        n = int(torch.randint(6, 30, (1,), generator=g))
+        f = tmp_path / f"data_{i}.ckpt"
+        torch.save({"hidden_state": torch.randn(n, d, generator=g).half(), "hidden_state_layer2": torch.randn(n, d, generator=g).half(),
+                    "input_ids": torch.randint(3, V, (n,), generator=g), "loss_mask": (torch.rand(n, generator=g) > 0.3).long()}, f)
+        files.append(str(f))
+    sd = {PARAM_KEYS["q_proj"]: torch.randn(d, d, generator=g) / 8, PARAM_KEYS["k_proj"]: torch.randn(d // 2, d, generator=g) / 8,
+          PARAM_KEYS["v_proj"]: torch.randn(d // 2, d, generator=g) / 8, PARAM_KEYS["o_proj"]: torch.randn(d, d, generator=g) / 8,
+          PARAM_KEYS["input_layernorm"]: torch.ones(d), PARAM_KEYS["norm"]: torch.ones(d)}
+    head = torch.randn(V, d, generator=g) * 0.3
+    mk = lambda: AdapterTrainer(shape, sd, head, dtype=torch.float16, lr=1e-3, num_warmup_steps=2, total_steps=100)
+    a = mk()
+    r0 = train_epoch(a, files, 2, bs=2, seed=0, log=lambda *_: None)
+    assert r0["batches"] == 4 and 0.0 <= r0["accuracy"] <= r0["top2"] <= r0["top3"] <= 1.0
+    a.save_state(str(tmp_path / "state_0.pt"))
+    r1 = train_epoch(a, files, 2, bs=2, seed=1, log=lambda *_: None)
+    b = mk()
+    b.load_state(str(tmp_path / "state_0.pt"))
+    r1b = train_epoch(b, files, 2, bs=2, seed=1, log=lambda *_: None)
+    assert r1 == r1b
+    for k, v in a.state_dict().items():
+        assert torch.equal(v, b.state_dict()[k]), k
