@@ -146,8 +146,33 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
 #endif
     if (loader) {
         kg_u4 sx[XS][GEMM_STAGE];
+        // RoPE epilogue: the cos / sin rows of the pass's positions go to their own LDS region now, in the shadow
+        // of the first X round trip (requested first, so waiting for them never waits for X)
+        constexpr int RS = (EPI == EPI_ROPE_KV) ? 16 : 1;       // 16-byte pieces per loader thread: rows x head_dim <= 128 x 128 floats
+        kg_u4 rsv[RS];
+        if (EPI == EPI_ROPE_KV) {
+            const int half = a.head_dim >> 1, ppr = a.head_dim >> 2;          // pieces per row
+#pragma unroll
+            for (int j = 0; j < RS; ++j) {
+                const int q = ltid + j * (GEMM_LW * 64), m = q / ppr, c4 = (q - m * ppr) * 4;
+                rsv[j] = kg_u4{0u, 0u, 0u, 0u};
+                if (m < M) {
+                    const size_t p = (size_t)(pos0 + m) * half;
+                    rsv[j] = *(const kg_u4*)((c4 < half) ? a.rope_cos + p + c4 : a.rope_sin + p + c4 - half);
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < XS; ++i) stage_load(sx[i], i);
+        if (EPI == EPI_ROPE_KV) {
+            const int ppr = a.head_dim >> 2;
+            char* rope_side = smem + 2 * KG_GEMM_ROWS * GEMM_XROW;
+#pragma unroll
+            for (int j = 0; j < RS; ++j) {
+                const int q = ltid + j * (GEMM_LW * 64);
+                if (q < KG_GEMM_ROWS * ppr) *(kg_u4*)(rope_side + (size_t)q * 16) = rsv[j];
+            }
+        }
         stage_store(sx[0], xs0);
         stage_load(sx[0], XS);
         __syncthreads();
@@ -220,7 +245,8 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
         }
         return;
     }
-    char* side = (EPI == EPI_RESID) ? xs0 + (size_t)(loader ? 0 : wave) * GEMM_RPW * KG_GEMM_ROWS * 32 : xs0;
+    char* side = (EPI == EPI_RESID) ? xs0 + (size_t)(loader ? 0 : wave) * GEMM_RPW * KG_GEMM_ROWS * 32
+               : (EPI == EPI_ROPE_KV) ? smem + 2 * KG_GEMM_ROWS * GEMM_XROW : xs0;       // cos / sin rows: staged by the loader waves at entry
     if (EPI == EPI_RESID && !loader) {
         const unsigned short* res = (const unsigned short*)a.resid;
 #pragma unroll
@@ -229,13 +255,6 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
                 const int m = e >> 4, n = (rg0 + j) * 16 + (e & 15);
                 ((unsigned short*)side)[j * KG_GEMM_ROWS * 16 + e] = (n < a.N) ? res[(size_t)m * a.resid_stride + n] : (unsigned short)0;
             }
-    } else if (EPI == EPI_ROPE_KV) {
-        const int half = a.head_dim >> 1;
-        for (int i = tid; i < M * a.head_dim; i += (GEMM_NW + GEMM_LW) * 64) {
-            const int m = i / a.head_dim, jj = i - m * a.head_dim;
-            const size_t p = (size_t)(pos0 + m) * half;
-            ((float*)side)[i] = (jj < half) ? a.rope_cos[p + jj] : a.rope_sin[p + jj - half];
-        }
     }
     __syncthreads();
     if (loader) { KG_TSTAMP(a, 7); return; }
@@ -343,13 +362,16 @@ int kg_gemm_grid_x(int N, int ksplit) {
     gemm_geometry(G, ksplit > 1 ? ksplit : 1, &nw, &rpw);
     return (G + nw * rpw - 1) / (nw * rpw);
 }
-static size_t gemm_smem() { return (size_t)2 * KG_GEMM_ROWS * GEMM_XROW; }
+static size_t gemm_smem(int epi = -1, int head_dim = 128) {
+    // two X^T buffers; the RoPE epilogue adds the cos / sin rows of the pass [rows][head_dim] floats
+    return (size_t)2 * KG_GEMM_ROWS * GEMM_XROW + ((epi == EPI_ROPE_KV || epi < 0) ? (size_t)KG_GEMM_ROWS * head_dim * 4 : 0);
+}
 
 template <int DT, int NW, int RPW>
 static int launch_epi(const KgLinArgs& a, int epi, hipStream_t st) {
     const int G = (a.N + 15) / 16;
     const dim3 grid((G + NW * RPW - 1) / (NW * RPW), a.ksplit > 1 ? a.ksplit : 1), block((NW + GEMM_LW) * 64);
-    const size_t smem = gemm_smem();
+    const size_t smem = gemm_smem(epi, a.head_dim);
     switch (epi) {
     case EPI_STORE: hipLaunchKernelGGL((kg_gemm_kernel<DT, EPI_STORE, NW, RPW>), grid, block, smem, st, a); break;
     case EPI_RESID: hipLaunchKernelGGL((kg_gemm_kernel<DT, EPI_RESID, NW, RPW>), grid, block, smem, st, a); break;
@@ -404,7 +426,7 @@ int kg_launch_gemm(const KgLinArgs& a_in, int dtype, int pro, int epi, hipStream
         if (epi == EPI_RESID && pro == PRO_NONE && a.kpart && G <= 2 * g_gemm_ncu && a.N % 16 == 0) ks = NB >= 16 ? 4 : (NB >= 8 ? 2 : 1);
         a.ksplit = ks;
     }
-    if (epi == EPI_ROPE_KV && (size_t)KG_GEMM_ROWS * a.head_dim * 4 > (size_t)2 * KG_GEMM_ROWS * GEMM_XROW) return -1;     // cos/sin rows reuse both X buffers
+    if (epi == EPI_ROPE_KV && (a.head_dim > 128 || (a.head_dim & 7) || !a.rope_cos || !a.rope_sin)) return -1;     // the loader waves stage rows x head_dim <= 128 x 128 floats
     int rc;
     if (pro != PRO_NONE) return -1;          // rows are normalised by kg_launch_rmsnorm before the pass
     rc = (dtype == KG_F16) ? launch_nw<KG_F16>(a, epi, st) : launch_nw<KG_BF16>(a, epi, st);
