@@ -15,7 +15,11 @@ model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, L, r
 eng = model.engine
 for kv in [a for a in sys.argv[1:] if "=" in a]:
     k, v = kv.split("=")
-    eng.set_tuning(**{k: int(v)})
+    if "." in v:      # float keys
+        import ctypes
+        eng.lib.kg_session_setf(eng._handle, k.encode(), ctypes.c_float(float(v)))
+    else:
+        eng.set_tuning(**{k: int(v)})
 for op in (() if "--short" in sys.argv else ("qkv", "o", "gateup", "down", "head")):
     r = []
     for rows in (1, 7):

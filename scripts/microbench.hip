@@ -14,6 +14,7 @@ __device__ unsigned long long kg_lin_tlog[64 * 1024 * 8];
 void kg_set_error(const char*, hipError_t) {}
 
 __global__ void k_empty() {}
+__global__ void k_xcc(int* out) { int v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); if (threadIdx.x == 0) out[blockIdx.x] = v & 15; }
 __global__ void k_flag(const int* f, int* o) { if (*f == 0) return; o[threadIdx.x] = 1; }
 __global__ void k_stream_read(const kg_u4* p, size_t n16, unsigned* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
@@ -348,6 +349,27 @@ int main(int argc, char** argv) {
         }
         printf("gap prev-end -> first entry %.2f us | entry skew %.2f | entry->params %.2f | params->X in LDS %.2f | X->first row group reduced %.2f | -> end %.2f | end skew %.2f\n",
                acc[0] / cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[6] / cnt, acc[5] / cnt);
+        {   // when do the blocks of each index residue mod 8 (= one XCD each) end, relative to the launch's first entry?
+            double e8[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int n8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            double mx8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 1; i < nlaunch; ++i) {
+                unsigned long long first_entry = ~0ull;
+                for (int b = 0; b < nb; ++b) { const unsigned long long e0 = t[((size_t)i * nb + b) * 8]; if (e0 < first_entry) first_entry = e0; }
+                for (int b = 0; b < nb; ++b) {
+                    const double e = (double)(t[((size_t)i * nb + b) * 8 + 4] - first_entry) * 0.01;
+                    e8[b & 7] += e; n8[b & 7]++; if (e > mx8[b & 7]) mx8[b & 7] = e;
+                }
+            }
+            int* xo; CK(hipMalloc(&xo, 64 * sizeof(int)));
+            hipLaunchKernelGGL(k_xcc, dim3(16), dim3(64), 0, st, xo);
+            int xh[16]; CK(hipMemcpyAsync(xh, xo, sizeof(xh), hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+            printf("   XCD of blocks 0..15 of a launch on this stream:");
+            for (int b = 0; b < 16; ++b) printf(" %d", xh[b]);
+            printf("\n");
+            printf("   block end after first entry, by block index mod 8 (mean / max us):");
+            for (int x = 0; x < 8; ++x) printf(" %d: %.1f / %.1f |", x, e8[x] / n8[x], mx8[x]);
+            printf("\n");
+        }
         printf("   thread 0 of a block: params -> first two weight batches requested %.2f us | -> its X share in LDS %.2f | -> block barrier passed %.2f | the block's last wave enters %.2f us after its first\n",
                acc[7] / cnt, acc[8] / cnt, acc[3] / cnt - acc[7] / cnt - acc[8] / cnt, acc[9] / cnt);
         CK(hipGraphExecDestroy(ge));
