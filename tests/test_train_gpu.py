@@ -295,3 +295,37 @@ def test_epoch_over_hidden_state_files_and_resume(tmp_path):
     assert r1 == r1b
     for k, v in a.state_dict().items():
         assert torch.equal(v, b.state_dict()[k]), k
+
+
+def test_command_line_trains_two_epochs_and_writes_an_adapter_the_decoder_loads(tmp_path, capsys):
+    """python -m kangaroo_amd.train with the flags of train.py:2-13: epoch 0, then epoch 1 resuming from the saved
+    state; the adapter file it leaves behind has the reference's key names and drives a decode."""
+    import json
+    from kangaroo_amd.config import get_shape
+    from kangaroo_amd.train import main
+    from kangaroo_amd.weights import Recipe, load_adapter_state_dict, save_synthetic_checkpoint, synth_state_dicts
+    shape = get_shape("tiny")
+    base, adapter = synth_state_dicts(shape, 2, seed=1, dtype=torch.float16, recipe=Recipe())
+    mdir, adir, ddir, cdir = (str(tmp_path / n) for n in ("model", "adapter", "data", "ckpt"))
+    save_synthetic_checkpoint(mdir, adir, shape, base, adapter)
+    os.makedirs(ddir)
+    g = torch.Generator().manual_seed(9)
+    d = shape.hidden_size
+    for i in range(10):
+        n = int(torch.randint(5, 24, (1,), generator=g))
+        torch.save({"hidden_state": torch.randn(n, d, generator=g).half(), "hidden_state_layer2": torch.randn(n, d, generator=g).half(),
+                    "input_ids": torch.randint(3, shape.vocab_size, (n,), generator=g), "loss_mask": torch.ones(n, dtype=torch.long)}, os.path.join(ddir, f"data_{i}.ckpt"))
+    common = ["--basepath", mdir, "--configpath", os.path.join(adir, "config.json"), "--tmpdir", ddir, "--cpdir", cdir, "--bs", "2", "--lr", "1e-3"]
+    main(common + ["--start", "0"])
+    main(common + ["--start", "1"])
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert [l["epoch"] for l in lines] == [0, 1] and all(l["batches"] == 4 for l in lines)       # 95 % of 10 files = 9, batches of 2
+    assert os.path.exists(os.path.join(cdir, "state_0.pt")) and os.path.exists(os.path.join(cdir, "state_1.pt"))
+    trained = load_adapter_state_dict(cdir)
+    assert set(trained) == set(adapter)
+    from kangaroo_amd.inference import kangaroo_forward
+    from kangaroo_amd.kangaroo_model import KangarooModel
+    model = KangarooModel.from_state_dicts(shape, base, trained, torch.float16, 2)
+    ids = torch.randint(3, shape.vocab_size, (1, 9), generator=g)
+    out = kangaroo_forward(ids.cuda(), model, 2, 12)
+    assert len(out[0][0]) > 9
