@@ -308,13 +308,26 @@ def test_command_line_trains_two_epochs_and_writes_an_adapter_the_decoder_loads(
     base, adapter = synth_state_dicts(shape, 2, seed=1, dtype=torch.float16, recipe=Recipe())
     mdir, adir, ddir, cdir = (str(tmp_path / n) for n in ("model", "adapter", "data", "ckpt"))
     save_synthetic_checkpoint(mdir, adir, shape, base, adapter)
-    os.makedirs(ddir)
     g = torch.Generator().manual_seed(9)
-    d = shape.hidden_size
+    # the hidden-state files come from the device prefill (data/ge_data_all_vicuna.py:139-171) and agree with the oracle
+    from kangaroo_amd.gen_data import generate
+    from kangaroo_amd.kangaroo_model import KangarooModel
+    from oracle import kangaroo_oracle as ko
+    gen_model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, 2)
+    samples = []
     for i in range(10):
-        n = int(torch.randint(5, 24, (1,), generator=g))
-        torch.save({"hidden_state": torch.randn(n, d, generator=g).half(), "hidden_state_layer2": torch.randn(n, d, generator=g).half(),
-                    "input_ids": torch.randint(3, shape.vocab_size, (n,), generator=g), "loss_mask": torch.ones(n, dtype=torch.long)}, os.path.join(ddir, f"data_{i}.ckpt"))
+        n = int(torch.randint(5, 24, (1,), generator=g)) if i else 140       # one sample long enough for the 128-row prefill passes
+        samples.append((torch.randint(3, shape.vocab_size, (1, n), generator=g), (torch.rand(n, generator=g) > 0.2).long()))
+    assert generate(gen_model, samples, ddir) == 10 and len(os.listdir(ddir)) == 10
+    rec = torch.load(os.path.join(ddir, "data_3.ckpt"), weights_only=True)
+    assert set(rec) == {"input_ids", "loss_mask", "hidden_state_layer2", "hidden_state"}
+    om = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), base, adapter, 2)
+    ref = om.base_model(samples[3][0])
+    for key, want in (("hidden_state_layer2", ref.hidden_states[2][0]), ("hidden_state", ref.hidden_states[-1][0])):
+        err = float((rec[key].float() - want).abs().max())
+        assert err <= 1e-2 * float(want.abs().max()), (key, err)
+    assert torch.equal(rec["input_ids"], samples[3][0][0]) and torch.equal(rec["loss_mask"], samples[3][1])
+    del gen_model
     common = ["--basepath", mdir, "--configpath", os.path.join(adir, "config.json"), "--tmpdir", ddir, "--cpdir", cdir, "--bs", "2", "--lr", "1e-3"]
     main(common + ["--start", "0"])
     main(common + ["--start", "1"])
@@ -324,7 +337,6 @@ def test_command_line_trains_two_epochs_and_writes_an_adapter_the_decoder_loads(
     trained = load_adapter_state_dict(cdir)
     assert set(trained) == set(adapter)
     from kangaroo_amd.inference import kangaroo_forward
-    from kangaroo_amd.kangaroo_model import KangarooModel
     model = KangarooModel.from_state_dicts(shape, base, trained, torch.float16, 2)
     ids = torch.randint(3, shape.vocab_size, (1, 9), generator=g)
     out = kangaroo_forward(ids.cuda(), model, 2, 12)
