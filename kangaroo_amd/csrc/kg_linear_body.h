@@ -239,12 +239,20 @@ __device__ __forceinline__ void prologue_load(const KgLinArgs& a, ProRegs<NS>& p
     const int K = a.K, nchunk = K >> 3;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0,
         (int)(((size_t)(M - 1 + row_off) * a.x_stride + K) * 2), 0x00020000);
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
+    // A load whose offset is out of range moves no data but still takes its turn in the CU's address path (measured:
+    // as long as a real one), so the slots beyond the first 8 are only requested when the pass has rows for them.
+    // The branch is block-uniform and both sides keep a fixed number of loads, so the counted waits stay exact enough.
+    auto load_slot = [&](int i) {
         const int m = i / SETS, c = tid + (i % SETS) * nthreads;
         const bool ok = (m < M) && (c < nchunk);
         const unsigned off = ok ? (unsigned)(((size_t)(m + row_off) * a.x_stride) * 2 + (size_t)c * 16) : 0xFFFFFFFFu;
         pr.v[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, COH_LD ? KG_AUX_COH : 0);
+    };
+#pragma unroll
+    for (int i = 0; i < (NS < 8 ? NS : 8); ++i) load_slot(i);
+    if (NS > 8 && M * SETS > 8) {
+#pragma unroll
+        for (int i = 8; i < NS; ++i) load_slot(i);
     }
     if (PRO == PRO_RMSNORM) {
         const __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc((void*)a.norm_w, 0, K * 2, 0x00020000);
@@ -263,24 +271,35 @@ __device__ __forceinline__ void prologue_finish(const KgLinArgs& a, const ProReg
     float ss[RM];
 #pragma unroll
     for (int m = 0; m < RM; ++m) ss[m] = 0.f;
+    const bool upper = NS > 8 && M * SETS > 8;             // slots 8.. were requested (see prologue_load)
     if (PRO == PRO_RMSNORM) {
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
+        auto add_slot = [&](int i) {
             const int m = i / SETS, c = tid + (i % SETS) * nthreads;
             if (i / SETS < RM) {
                 if (m < M && c < nchunk) ss[i / SETS < RM ? i / SETS : 0] += sum_sq8<DT>(pr.v[i]);
             }
+        };
+#pragma unroll
+        for (int i = 0; i < (NS < 8 ? NS : 8); ++i) add_slot(i);
+        if (upper) {
+#pragma unroll
+            for (int i = 8; i < NS; ++i) add_slot(i);
         }
         rms_row_factors<RM>(ss, red2, M, a.K, a.eps, lane, wave, nwaves);
     }
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
+    auto store_slot = [&](int i) {
         const int m = i / SETS, c = tid + (i % SETS) * nthreads;
         if (i / SETS < RM) {
             if (m < M && c < nchunk)
                 *(kg_u4*)(xs + (size_t)m * xs_stride + (size_t)c * 16) =
                     (PRO == PRO_NONE) ? pr.v[i] : rms_apply<DT>(pr.v[i], pr.gw[i % SETS], ss[i / SETS < RM ? i / SETS : 0]);
         }
+    };
+#pragma unroll
+    for (int i = 0; i < (NS < 8 ? NS : 8); ++i) store_slot(i);
+    if (upper) {
+#pragma unroll
+        for (int i = 8; i < NS; ++i) store_slot(i);
     }
 }
 
@@ -395,22 +414,36 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
     const int nchunk_ = a.K >> 3;
     const __amdgpu_buffer_rsrc_t xrow_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0,
         ROWPRO ? (int)(((size_t)(M - 1) * a.x_stride + a.K) * 2) : 0, 0x00020000);
-    auto rowpro_load = [&](int row) {
+    // Chunks 0..7 of a row (K <= 4096) are always requested, chunks 8..11 and 12..15 only when the row has them: an
+    // out-of-range load moves no data but occupies the CU's address path like a real one (gate/up at K = 4096:
+    // 0.9 us per launch).  The conditions are block-uniform.
+    const bool rp_t1 = ROWPRO && nchunk_ > 512, rp_t2 = ROWPRO && nchunk_ > 768;
+    auto rp_tiers = [&](auto&& f) {
 #pragma unroll
-        for (int i = 0; i < NCM; ++i) {
+        for (int i = 0; i < (NCM < 8 ? NCM : 8); ++i) f(i);
+        if (rp_t1) {
+#pragma unroll
+            for (int i = 8; i < (NCM < 12 ? NCM : 12); ++i) f(i);
+        }
+        if (rp_t2) {
+#pragma unroll
+            for (int i = 12; i < NCM; ++i) f(i);
+        }
+    };
+    auto rowpro_load = [&](int row) {
+        rp_tiers([&](int i) {
             const int c = lane + 64 * i;
             rx[i] = __builtin_amdgcn_raw_buffer_load_b128(xrow_rsrc, (row < M && c < nchunk_) ? (unsigned)(((size_t)row * a.x_stride) * 2 + (size_t)c * 16) : 0xFFFFFFFFu,
                                                           0, COH_LD ? KG_AUX_COH : 0);
-        }
+        });
     };
     if (ROWPRO) {
         const __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc((void*)a.norm_w, 0, a.K * 2, 0x00020000);
         rowpro_load(wave);
-#pragma unroll
-        for (int i = 0; i < NCM; ++i) {
+        rp_tiers([&](int i) {
             const int c = lane + 64 * i;
             rgm[i] = __builtin_amdgcn_raw_buffer_load_b128(nr, (wave < M && c < nchunk_) ? (unsigned)c * 16u : 0xFFFFFFFFu, 0, 0);
-        }
+        });
     } else if (MODE != MODE_MFMA_GX && pro_fast) {
         if (pro_sets == 1) prologue_load<PRO, NS, 1, COH_LD>(a, pr, M, row_off, tid, nthreads);
         else prologue_load<PRO, NS, 2, COH_LD>(a, pr, M, row_off, tid, nthreads);
@@ -515,14 +548,12 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
         for (int row = wave; row < M; row += nwaves) {          // wave-uniform trip count
             if (row != wave) rowpro_load(row);
             float ssq = 0.f;
-#pragma unroll
-            for (int i = 0; i < NCM; ++i) ssq += T::sum_sq8(rx[i]);      // chunks out of range came back as zeros
+            rp_tiers([&](int i) { ssq += T::sum_sq8(rx[i]); });          // requested chunks out of range came back as zeros
             const float rstd = rsqrtf(kg_wave_sum_dpp(ssq) / (float)a.K + a.eps);
-#pragma unroll
-            for (int i = 0; i < NCM; ++i) {
+            rp_tiers([&](int i) {
                 const int c = lane + 64 * i;
                 if (c < nchunk_) *(kg_u4*)(xs + (size_t)row * xs_stride + (size_t)c * 16) = T::rms_apply(rx[i], rgm[i], rstd);
-            }
+            });
         }
     } else if (MODE != MODE_MFMA_GX) {
         if (!pro_fast) prologue_slow<DT, PRO, RM, COH_LD>(a, xs, xs_stride, red2, M, row_off, tid, nthreads, lane, wave, nwaves);
