@@ -573,7 +573,7 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
     // two ahead (the two buffers alternate, so no register copies and up to 2*KG_U tiles stay
     // in flight per wave), and at the end of a row group reduce across waves and run the
     // epilogue.
-    auto step = [&](kg_u4 (&wv)[KG_U], kg_u4 (&xv)[KG_U], int which) {
+    auto step = [&](kg_u4 (&wv)[KG_U], kg_u4 (&xv)[KG_U], int which, bool refill) {
         char* xslot = xs + (size_t)(wave * 2 + which) * a.gx_slot_rows * GX_ROW;      // MODE_MFMA_GX only
         if (MODE == MODE_MFMA_GX) {
 #pragma unroll
@@ -600,9 +600,11 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
                 acc = T::mfma(w, x, acc);
             }
         }
-        issue(wv, xv, lrg, lt);
-        lt += KG_U;
-        if (lt >= t1) { lt = t0; lrg += gridDim.x; }
+        if (refill) {
+            issue(wv, xv, lrg, lt);
+            lt += KG_U;
+            if (lt >= t1) { lt = t0; lrg += gridDim.x; }
+        }
         ct += KG_U;
         if (ct >= t1 && rg < G) {
             // ---- cross-wave reduction through LDS (slot alternates per row group) ----
@@ -634,13 +636,22 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
             acc = kg_f4{0.f, 0.f, 0.f, 0.f}; acc0 = 0.f; acc1 = 0.f;
         }
     };
-    // Steps come in pairs with a single back edge, so that at the top of the loop the other
-    // buffer's refill is always "newer" and the counted waits keep it in flight.  A trailing
-    // step past the last row group only sees out-of-range (zero) tiles and skips the epilogue.
-    do {
-        step(bufA, bufAx, 0);
-        step(bufB, bufBx, 1);
-    } while (rg < G);
+    // A wave consumes nsteps batches (one per KG_U tiles of its k range and row group; a wave without a k range
+    // still takes one step per row group for the block barriers).  Step k refills its buffer with batch k + 2.
+    // The main loop runs the pairs of steps whose refills both exist: a single back edge, two batches in flight,
+    // counted waits.  The last (up to three) steps stand outside it and request nothing: an out-of-range request
+    // moves no data but still occupies the CU's address path, which for a projection of two batches per wave
+    // (o_proj) sat between the two consumes (measured 0.45 us per launch).
+    const int nsteps = nrg_blk * max(1, (t1 - t0 + KG_U - 1) / KG_U);
+    int ks = 0;
+    while (ks + 3 < nsteps) {
+        step(bufA, bufAx, 0, true);
+        step(bufB, bufBx, 1, true);
+        ks += 2;
+    }
+    if (ks < nsteps) { step(bufA, bufAx, 0, ks + 2 < nsteps); ++ks; }
+    if (ks < nsteps) { step(bufB, bufBx, 1, false); ++ks; }
+    if (ks < nsteps) { step(bufA, bufAx, 0, false); ++ks; }
     if (EPI == EPI_HEAD) {
         // merge the 8 pair-threads of each column, then one record per (block, column)
         const int n_epi = (MODE == MODE_VEC) ? 8 : 128;
