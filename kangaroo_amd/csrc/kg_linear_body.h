@@ -508,12 +508,19 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
     // never waits for those weights (the counter retires in order).
     auto issue_x = [&](kg_u4 (&xv)[KG_U], int lrg, int lt) {
         if (MODE == MODE_MFMA_GX) {
-#pragma unroll
-            for (int j = 0; j < KG_U; ++j) {
+            auto load_piece = [&](int j) {
                 const int flat = j * 64 + lane, row = flat >> 5, ch = flat & 31;
                 const bool okx = (lrg < G) && (row < M) && (lt + (ch >> 2) < t1);
                 const unsigned xo = okx ? (unsigned)(((size_t)row * a.x_stride) * 2) + (unsigned)lt * 64u + (unsigned)ch * 16u : 0xFFFFFFFFu;
                 xv[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo, 0, COH_LD ? KG_AUX_COH : 0);
+            };
+            // load j covers rows 2j and 2j + 1: with 8-row slots the upper half would request nothing, and a request
+            // out of range still takes its turn in the address path (the branch is block-uniform)
+#pragma unroll
+            for (int j = 0; j < KG_U / 2; ++j) load_piece(j);
+            if (a.gx_slot_rows > 8) {
+#pragma unroll
+                for (int j = KG_U / 2; j < KG_U; ++j) load_piece(j);
             }
         }
     };
@@ -577,9 +584,16 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
         char* xslot = xs + (size_t)(wave * 2 + which) * a.gx_slot_rows * GX_ROW;      // MODE_MFMA_GX only
         if (MODE == MODE_MFMA_GX) {
 #pragma unroll
-            for (int j = 0; j < KG_U; ++j) {
+            for (int j = 0; j < KG_U / 2; ++j) {
                 const int flat = j * 64 + lane, row = flat >> 5, ch = flat & 31;
-                if (row < a.gx_slot_rows) *(kg_u4*)(xslot + row * GX_ROW + ch * 16) = xv[j];
+                *(kg_u4*)(xslot + row * GX_ROW + ch * 16) = xv[j];
+            }
+            if (a.gx_slot_rows > 8) {
+#pragma unroll
+                for (int j = KG_U / 2; j < KG_U; ++j) {
+                    const int flat = j * 64 + lane, row = flat >> 5, ch = flat & 31;
+                    *(kg_u4*)(xslot + row * GX_ROW + ch * 16) = xv[j];
+                }
             }
         }
 #pragma unroll
