@@ -383,6 +383,7 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
     if (idle) {
         // same barrier sequence as the working waves: the norm's (if any), one after the prologue, one per row group
         if (PRO == PRO_RMSNORM && MODE == MODE_VEC) __syncthreads();
+        if (MODE == MODE_MFMA && PRO == PRO_RMSNORM && a.K * 2 <= 2 * nwaves * PART * 4) __syncthreads();     // gamma handed round through LDS
         __syncthreads();
         for (int i = 0; i < nrg_blk; ++i) __syncthreads();
         gb->arrive();
@@ -437,13 +438,24 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
                                                           0, COH_LD ? KG_AUX_COH : 0);
         });
     };
+    // gamma: every wave with a row needs all of it.  When it fits the (still unused) cross-wave reduction area the
+    // block fetches it ONCE, 16 bytes per thread, and hands it round through LDS: per block 8 wave-level loads
+    // instead of 8 per row, and the CU's address path, which the burst of requests at kernel entry saturates, is
+    // free that much earlier.  Waves without a row request nothing at all.
+    const bool g_lds = ROWPRO && a.K * 2 <= 2 * nwaves * PART * 4;          // block-uniform
+    kg_u4 gq[2];
     if (ROWPRO) {
         const __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc((void*)a.norm_w, 0, a.K * 2, 0x00020000);
-        rowpro_load(wave);
-        rp_tiers([&](int i) {
-            const int c = lane + 64 * i;
-            rgm[i] = __builtin_amdgcn_raw_buffer_load_b128(nr, (wave < M && c < nchunk_) ? (unsigned)c * 16u : 0xFFFFFFFFu, 0, 0);
-        });
+        if (wave < M) rowpro_load(wave);
+        if (g_lds) {
+            gq[0] = __builtin_amdgcn_raw_buffer_load_b128(nr, (tid < nchunk_) ? (unsigned)tid * 16u : 0xFFFFFFFFu, 0, 0);
+            if (nchunk_ > nthreads) gq[1] = __builtin_amdgcn_raw_buffer_load_b128(nr, (tid + nthreads < nchunk_) ? (unsigned)(tid + nthreads) * 16u : 0xFFFFFFFFu, 0, 0);
+        } else if (wave < M) {
+            rp_tiers([&](int i) {
+                const int c = lane + 64 * i;
+                rgm[i] = __builtin_amdgcn_raw_buffer_load_b128(nr, (c < nchunk_) ? (unsigned)c * 16u : 0xFFFFFFFFu, 0, 0);
+            });
+        }
     } else if (MODE != MODE_MFMA_GX && pro_fast) {
         if (pro_sets == 1) prologue_load<PRO, NS, 1, COH_LD>(a, pr, M, row_off, tid, nthreads);
         else prologue_load<PRO, NS, 2, COH_LD>(a, pr, M, row_off, tid, nthreads);
@@ -535,10 +547,19 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
     else issue(bufA, bufAx, lrg, lt);
     lt += KG_U;
     if (lt >= t1) { lt = t0; lrg += gridDim.x; }
-    if (EARLY) issue_x(bufBx, lrg, lt);
-    else issue(bufB, bufBx, lrg, lt);
-    lt += KG_U;
-    if (lt >= t1) { lt = t0; lrg += gridDim.x; }
+    // M-row passes with a norm request their second batch only after the rows are in LDS.  The rows come
+    // from the memory side (another XCD wrote them) and land ~3.5 us after the request while every CU floods the
+    // same queues with weight requests; with both batches requested first, a wave reached its wait for the rows
+    // only after 2.5 us of issuing and the block's barrier fell 6 us after entry.  One batch ahead, the rows are
+    // in LDS after 4.3 us and the second batch is in flight while the first is consumed (gate/up -0.6 us per
+    // launch; the other prologues and the 1-row kernels measured the same or slower this way).
+    constexpr bool DEFER_B = ROWPRO && !EARLY;
+    if (!DEFER_B) {
+        if (EARLY) issue_x(bufBx, lrg, lt);
+        else issue(bufB, bufBx, lrg, lt);
+        lt += KG_U;
+        if (lt >= t1) { lt = t0; lrg += gridDim.x; }
+    }
 
     KG_TSTAMP(a, 5);
     if (side_fast) {
@@ -552,20 +573,38 @@ __device__ __forceinline__ void kg_linear_body(const KgLinArgs& a, char* smem, K
         }
     }
     if (ROWPRO) {
-        for (int row = wave; row < M; row += nwaves) {          // wave-uniform trip count
-            if (row != wave) rowpro_load(row);
+        char* gam = (char*)part;                                // free until the first row group is reduced
+        if (g_lds) {
+            if (tid < nchunk_) *(kg_u4*)(gam + (size_t)tid * 16) = gq[0];
+            if (nchunk_ > nthreads && tid + nthreads < nchunk_) *(kg_u4*)(gam + (size_t)(tid + nthreads) * 16) = gq[1];
+        }
+        auto row_factor = [&]() {
             float ssq = 0.f;
             rp_tiers([&](int i) { ssq += T::sum_sq8(rx[i]); });          // requested chunks out of range came back as zeros
-            const float rstd = rsqrtf(kg_wave_sum_dpp(ssq) / (float)a.K + a.eps);
+            return rsqrtf(kg_wave_sum_dpp(ssq) / (float)a.K + a.eps);
+        };
+        float rstd = 0.f;
+        if (wave < M) rstd = row_factor();
+        if (g_lds) __syncthreads();                             // gamma is in LDS
+        for (int row = wave; row < M; row += nwaves) {          // wave-uniform trip count
+            if (row != wave) { rowpro_load(row); rstd = row_factor(); }
             rp_tiers([&](int i) {
                 const int c = lane + 64 * i;
-                if (c < nchunk_) *(kg_u4*)(xs + (size_t)row * xs_stride + (size_t)c * 16) = T::rms_apply(rx[i], rgm[i], rstd);
+                if (c < nchunk_) {
+                    const kg_u4 gv = g_lds ? *(const kg_u4*)(gam + (size_t)c * 16) : rgm[i];
+                    *(kg_u4*)(xs + (size_t)row * xs_stride + (size_t)c * 16) = T::rms_apply(rx[i], gv, rstd);
+                }
             });
         }
     } else if (MODE != MODE_MFMA_GX) {
         if (!pro_fast) prologue_slow<DT, PRO, RM, COH_LD>(a, xs, xs_stride, red2, M, row_off, tid, nthreads, lane, wave, nwaves);
         else if (pro_sets == 1) prologue_finish<DT, PRO, NS, RM, 1>(a, pr, xs, xs_stride, red2, M, tid, nthreads, lane, wave, nwaves);
         else prologue_finish<DT, PRO, NS, RM, 2>(a, pr, xs, xs_stride, red2, M, tid, nthreads, lane, wave, nwaves);
+    }
+    if (DEFER_B) {
+        issue(bufB, bufBx, lrg, lt);
+        lt += KG_U;
+        if (lt >= t1) { lt = t0; lrg += gridDim.x; }
     }
     KG_TSTAMP(a, 6);
     __syncthreads();

@@ -37,7 +37,8 @@ if "--prefill" in sys.argv:
               else f"prefill T0={plen:5d}: {min(ms):7.2f} ms", flush=True)
 if "--decode" in sys.argv:
     g = torch.Generator().manual_seed(1)
-    for plen in ((64,) if short else (64, 600, 1200)):
+    plens = (int(sys.argv[sys.argv.index("--plen") + 1]),) if "--plen" in sys.argv else ((64,) if short else (64, 600, 1200))
+    for plen in plens:
         ids = torch.randint(3, shape.vocab_size, (plen,), generator=g)
         eng.generate(ids, 16, mode="kangaroo")
         out, st = eng.generate(ids, 64 if short else 512, mode="kangaroo")
