@@ -206,6 +206,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank == 0:
+        # a line on stderr every 45 s: building the weights of the larger shapes takes minutes without any output,
+        # and job runners take a silent process for a hung one
+        import threading
+        t_start = time.time()
+        def _heartbeat():
+            while True:
+                time.sleep(45)
+                print(f"[bench] {a.model}: running, {time.time() - t_start:.0f} s", file=sys.stderr, flush=True)
+        threading.Thread(target=_heartbeat, daemon=True).start()
     if a.gpus != world:
         sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE is {world}: for N > 1 launch one rank per GPU with "
                  f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...`")
