@@ -333,7 +333,13 @@ static int grid_for(const kg_session* s, int N, int max_rows, int op) {
     // Balanced: with at most cap blocks a block walks k = ceil(G / cap) row groups; ceil(G / k) blocks do
     // that with every block within one group of k (1376 groups on 256 CUs: 230 blocks x 6 instead of
     // 96 blocks x 6 and 160 x 5; 320 groups: 160 x 2 instead of 64 x 2 and 192 x 1).
-    const int cap = g_ncu * s->bpc[mode][op];
+    // The projections that open with an RMSNorm of the X rows (qkv, gate/up, head) do best on about 200 of the 256
+    // CUs (measured at the 7B and 13B shapes, 1 and 7 rows: qkv 192 blocks x 4 groups against 256 x 3 -0.3 us,
+    // gate/up 197 x 7 against 230 x 6 -0.4 us, head 200 x 10 against 250 x 8 -0.5 us; 7B round -1.3 %): the weight
+    // stream is saturated well below 256 CUs and every block fewer is one prologue fewer in the opening burst.
+    // The residual projections (one row group per block at these shapes) want every CU.
+    const bool norm_op = (op == OP_QKV || op == OP_GATEUP || op == OP_HEAD);
+    const int cap = (norm_op ? g_ncu * 25 / 32 : g_ncu) * s->bpc[mode][op];
     if (cap >= G) return G;
     const int k = (G + cap - 1) / cap;
     return (G + k - 1) / k;
