@@ -56,6 +56,12 @@ struct KgAttnArgs {
     unsigned* counters;         // [4][H] arrival counters of the split merge; zero between launches
     void* out;                  // [n_rows, H*hd]
     int max_rows;               // upper bound of dyn->n_rows: <= 16, or <= KG_GEMM_ROWS for the MFMA kernel (16-row blocks on grid.z)
+    // MFMA kernel, optional: packed weights of the projection launched next (pf_groups row groups of pf_group_bytes,
+    // walked by pf_grid blocks), of which the blocks without keys pull the first pf_bytes_per_group bytes of every row
+    // group into the L2 of the XCD that will read them.  pf_w == NULL: nothing is fetched.
+    const void* pf_w;
+    int pf_groups, pf_group_bytes, pf_grid, pf_bytes_per_group;
+    int pf_min_chunks;          // fetch only when at least this many chunks hold keys: a shorter pass ends before the fetch does
 };
 int kg_launch_attn(const KgAttnArgs& a, int dtype, hipStream_t st);
 void kg_attn_init();

@@ -713,6 +713,14 @@ def test_attention_geometry_does_not_change_results():
         else:
             assert (out, st.accept_lengths, st.draft_lengths) == ref, (blocks, teams)
     eng.set_tuning(attn_blocks=16, attn_teams=1)
+    # blocks without keys fetch the head of the o_proj weight stream and discard it: off, whole row groups from the
+    # first chunk on, and the default share must all give the same tokens
+    keep = (eng.get_tuning("attn_prefetch"), eng.get_tuning("attn_prefetch_min"))
+    for share, first in ((1, 1), (9, 1), (4, 3)):
+        eng.set_tuning(attn_prefetch=share, attn_prefetch_min=first)
+        out, st = eng.generate(ids, 80, mode="kangaroo")
+        assert (out, st.accept_lengths, st.draft_lengths) == ref, (share, first)
+    eng.set_tuning(attn_prefetch=keep[0], attn_prefetch_min=keep[1])
 
 
 def test_zz_explained_cases_equal_the_allow_list():
