@@ -266,6 +266,7 @@ __global__ void __launch_bounds__(NT * ATT_NW * 64) kg_attn_mfma_kernel(const Kg
     if (c0 >= n_act) {
         if (a.pf_w && blockIdx.z == 0 && n_act >= a.pf_min_chunks) {
             const int n_idle_y = (int)gridDim.y - nblk_act;
+            for (int i = 0; i < a.pf_delay; i += 16) __builtin_amdgcn_s_sleep(16);
             attn_idle_prefetch(a, h, (h >> 3) * n_idle_y + ((int)blockIdx.y - nblk_act), (a.H >> 3) * n_idle_y, tid, NT * ATT_NW * 64);
         }
         return;

@@ -59,6 +59,7 @@ struct kg_session {
     int waves[2][5], bpc[2][5];
     int nblk[2][5];                    // > 0: block count of the op, overriding blocks-per-CU
     int attn_nsplit, attn_blocks, attn_teams;
+    int attn_prefetch_delay;           // the fetching blocks first sleep this many times 64 cycles, so the pass's own K/V requests are ahead of theirs
     int attn_prefetch_min;             // chunks that must hold keys before the fetch pays (a shorter attention pass ends before the fetch does)
     int attn_prefetch;                 // eighths of every o_proj row group that idle attention blocks pull into L2 (0: off)
     int v_transposed;
@@ -199,7 +200,7 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     s->bench_layers = s->sh.num_layers;
     s->vanilla_gemv = 0;
     s->attn_teams = 1;
-    s->attn_prefetch = 5; s->attn_prefetch_min = 6;
+    s->attn_prefetch = 5; s->attn_prefetch_min = 6; s->attn_prefetch_delay = 16;
     s->attn_blocks = 16;                         // one chunk per block: long contexts need many CUs pulling K/V (one CU sustains only ~60 GB/s)
     s->round_graph = nullptr; s->round_graph_steps = -1; s->vanilla_graph = nullptr;
     s->prog_n[0] = s->prog_n[1] = s->prog_n[2] = 0;
@@ -248,6 +249,7 @@ extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
     if (k == "accept_typical") { s->accept_typical = value >= 2 ? 1 : 0; done = true; }   // 1: off, 2: on
     if (k == "attn_teams") { if (value > 2) return fail(-1, "attn_teams is 1 or 2"); s->attn_teams = value; done = true; }
     if (k == "attn_prefetch") { if (value > 9) return fail(-1, "attn_prefetch is 1 (off) .. 9 (whole row groups)"); s->attn_prefetch = value - 1; done = true; }
+    if (k == "attn_prefetch_delay") { s->attn_prefetch_delay = value - 1; done = true; }
     if (k == "attn_prefetch_min") { s->attn_prefetch_min = value; done = true; }
     if (k == "attn_blocks") { if (value > 32) return fail(-1, "attn_blocks <= 32"); s->attn_blocks = value; done = true; }
     if (k == "persist") { s->persist = (value >= 2 && s->v_transposed && (g_ncu % 8) == 0) ? 1 : 0; done = true; }   // 1: off, 2: on
@@ -310,6 +312,7 @@ extern "C" int kg_session_get(kg_session* s, const char* key) {
     if (k == "attn_teams") return s->attn_teams;
     if (k == "attn_prefetch") return s->attn_prefetch + 1;
     if (k == "attn_prefetch_min") return s->attn_prefetch_min;
+    if (k == "attn_prefetch_delay") return s->attn_prefetch_delay + 1;
     if (k == "accept_top_k") return s->accept_top_k;
     if (k == "accept_typical") return s->accept_typical;
     if (k == "gemm_prefill") return s->gemm_prefill;
@@ -382,7 +385,7 @@ static int run_layer(kg_session* s, const kg_layer_weights& lw, void* kc, void* 
         a.nsplit = s->attn_nsplit; a.blocks_per_head = s->attn_blocks; a.teams = s->attn_teams; a.part_o = s->part_o; a.part_ml = s->part_ml; a.counters = s->attn_counters; a.out = s->attn_out; a.max_rows = max_rows;
         if (s->attn_prefetch > 0 && max_rows <= KG_MAX_ROWS) {
             a.pf_w = lw.wo; a.pf_groups = (d + 15) / 16; a.pf_group_bytes = (s->q_dim / 32) * 1024;
-            a.pf_grid = grid_for(s, d, max_rows, OP_O); a.pf_bytes_per_group = a.pf_group_bytes / 8 * s->attn_prefetch; a.pf_min_chunks = s->attn_prefetch_min;
+            a.pf_grid = grid_for(s, d, max_rows, OP_O); a.pf_bytes_per_group = a.pf_group_bytes / 8 * s->attn_prefetch; a.pf_min_chunks = s->attn_prefetch_min; a.pf_delay = s->attn_prefetch_delay;
         }
         KG_TRY(kg_launch_attn(a, dt, st));
     }

@@ -61,6 +61,7 @@ struct KgAttnArgs {
     // group into the L2 of the XCD that will read them.  pf_w == NULL: nothing is fetched.
     const void* pf_w;
     int pf_groups, pf_group_bytes, pf_grid, pf_bytes_per_group;
+    int pf_delay;               // the fetching blocks first sleep this many times 64 cycles
     int pf_min_chunks;          // fetch only when at least this many chunks hold keys: a shorter pass ends before the fetch does
 };
 int kg_launch_attn(const KgAttnArgs& a, int dtype, hipStream_t st);

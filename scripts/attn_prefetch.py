@@ -14,9 +14,9 @@ eng = model.engine
 g = torch.Generator().manual_seed(1)
 prompts = [torch.randint(3, shape.vocab_size, (n,), generator=g) for n in (64, 300, 600, 900, 1200, 1600)]
 ref = None
-for pf, pb in ((1, 1), (9, 1), (9, 3), (9, 5), (6, 1), (6, 3), (6, 5), (1, 1)):
-    eng.set_tuning(attn_prefetch=pf, attn_prefetch_extra=pb)
-    line = f"prefetch {pf - 1}/8, {pb - 1} extra blocks per head: "
+for pf, pb in ((1, 1), (6, 1), (6, 17), (6, 33), (6, 65), (9, 33), (1, 1)):
+    eng.set_tuning(attn_prefetch=pf, attn_prefetch_delay=pb)
+    line = f"prefetch {pf - 1}/8, delay {pb - 1} x 64 cycles: "
     outs = []
     for ids in prompts:
         eng.generate(ids, 16, mode="kangaroo")
