@@ -187,6 +187,10 @@ int kg_session_get(kg_session* s, const char* key);
 /* tuning knobs: "attn_nsplit" (number of fixed key chunks: fixes the boundaries of the attention
  * reduction), "attn_blocks" (blocks that share one head's chunks) and "attn_teams" (1 or 2 four-wave teams per
  * block working on different chunks at once): geometry only, results do not change;
+ * "attn_prefetch" (1: off, 1 + n: attention blocks whose chunks hold no keys yet read the first n/8 of every
+ * o_proj row group into the L2 their XCD shares with the o_proj blocks that follow; default 6),
+ * "attn_prefetch_min" (chunks in use from which they do so; default 6) and "attn_prefetch_delay" (1 + cycles / 64
+ * they wait first; default 17): timing only, the values read are discarded;
  * "<mode>_waves" and "<mode>_blocks_per_cu" for all linear ops of a mode, or "<mode>.<op>.waves" /
  * "<mode>.<op>.blocks_per_cu" for one, with mode in {vec (1 row), mfma (2..16 rows)} and op in
  * {qkv, o, gateup, down, head}: with at most cap = CUs * blocks_per_cu blocks a block walks
