@@ -207,15 +207,16 @@ __global__ void __launch_bounds__(ATT_NW * 64) kg_attn_kernel(const KgAttnArgs a
 // head's counter merges them (a chain of four round trips, ~6 us).
 // Blocks whose chunks hold no keys yet have nothing to do while the others sit in a chain of memory round trips that
 // leaves the memory system idle.  They fetch the head of the next projection's weight stream instead: consecutive
-// launches place block b on XCD (b + c) mod 8 with one c, so the blocks of head h (H a multiple of 8) share an XCD with
-// the consumer's blocks b = h mod 8, and what they read stays in that XCD's L2 for the consumer.  The values are
-// discarded; every address is range-checked by the buffer descriptor.
-__device__ __forceinline__ void attn_idle_prefetch(const KgAttnArgs& a, int h, int idle_idx, int idle_cnt, int tid, int nthr) {
+// launches place block b on XCD (b + c) mod 8 with one c, so a block with linear index b shares an XCD with the
+// consumer's blocks of the same index mod 8 (`rho`), and what it reads stays in that XCD's L2 for the consumer.  The
+// blocks of one XCD share out that XCD's bytes by (idle_idx, idle_cnt); an index nobody holds (head counts that are
+// not a multiple of 8) leaves its share unfetched.  The values are discarded; every address is range-checked by
+// the buffer descriptor.
+__device__ __forceinline__ void attn_idle_prefetch(const KgAttnArgs& a, unsigned rho, int idle_idx, int idle_cnt, int tid, int nthr) {
     const unsigned upg = (unsigned)a.pf_bytes_per_group >> 4;                 // 16-byte units fetched per row group
     const unsigned gpr = (unsigned)a.pf_groups >> 3;                          // row groups per XCD
     const unsigned U = gpr * upg;
     const unsigned u0 = (unsigned)((unsigned long long)U * idle_idx / idle_cnt), u1 = (unsigned)((unsigned long long)U * (idle_idx + 1) / idle_cnt);
-    const unsigned rho = (unsigned)h & 7u;
     const unsigned long long total = (unsigned long long)a.pf_groups * a.pf_group_bytes;
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.pf_w, 0, (int)(total > 0x7fffffffull ? 0x7fffffffull : total), 0x00020000);
     constexpr int PB = 8;
@@ -267,7 +268,8 @@ __global__ void __launch_bounds__(NT * ATT_NW * 64) kg_attn_mfma_kernel(const Kg
         if (a.pf_w && blockIdx.z == 0 && n_act >= a.pf_min_chunks) {
             const int n_idle_y = (int)gridDim.y - nblk_act;
             for (int i = 0; i < a.pf_delay; i += 16) __builtin_amdgcn_s_sleep(16);
-            attn_idle_prefetch(a, h, (h >> 3) * n_idle_y + ((int)blockIdx.y - nblk_act), (a.H >> 3) * n_idle_y, tid, NT * ATT_NW * 64);
+            attn_idle_prefetch(a, (unsigned)(h + a.H * (int)blockIdx.y) & 7u, (h >> 3) * n_idle_y + ((int)blockIdx.y - nblk_act), ((a.H + 7) >> 3) * n_idle_y,
+                               tid, NT * ATT_NW * 64);
         }
         return;
     }
@@ -445,8 +447,8 @@ void kg_attn_init() {
 
 int kg_launch_attn(const KgAttnArgs& a_in, int dtype, hipStream_t st) {
     KgAttnArgs a = a_in;
-    // the hand-over through L2 needs the heads and the consumer's blocks and row groups to fall evenly on the 8 XCDs
-    if (a.pf_w && ((a.H & 7) || (a.pf_grid & 7) || (a.pf_groups & 7) || a.pf_group_bytes <= 0 || a.pf_bytes_per_group < 16)) a.pf_w = nullptr;
+    // the hand-over through L2 needs the consumer's blocks and row groups to fall evenly on the 8 XCDs
+    if (a.pf_w && ((a.pf_grid & 7) || (a.pf_groups & 7) || a.pf_group_bytes <= 0 || a.pf_bytes_per_group < 16)) a.pf_w = nullptr;
     if (a.pf_w) a.pf_bytes_per_group = (a.pf_bytes_per_group > a.pf_group_bytes ? a.pf_group_bytes : a.pf_bytes_per_group) & ~15;
     if (!a.counters || a.nsplit < 1 || a.nsplit > KG_ATTN_MAX_SPLITS || a.max_rows < 1 || a.max_rows > (a.v_transposed ? KG_GEMM_ROWS : KG_MAX_ROWS) || a.H % a.Hkv != 0) return -1;
     if (a.v_transposed && (a.t_max % 32 != 0)) return -1;

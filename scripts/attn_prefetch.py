@@ -12,11 +12,14 @@ base, adapter = synth_state_dicts(shape, L, seed=0, dtype=torch.float16, recipe=
 model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, L, release_source=True)
 eng = model.engine
 g = torch.Generator().manual_seed(1)
-prompts = [torch.randint(3, shape.vocab_size, (n,), generator=g) for n in (64, 300, 600, 900, 1200, 1600)]
+prompts = [torch.randint(3, shape.vocab_size, (n,), generator=g) for n in (64, 200, 300, 450, 600, 900, 1200)]
 ref = None
-for pf, pb in ((1, 1), (6, 1), (6, 17), (6, 33), (6, 65), (9, 33), (1, 1)):
-    eng.set_tuning(attn_prefetch=pf, attn_prefetch_delay=pb)
-    line = f"prefetch {pf - 1}/8, delay {pb - 1} x 64 cycles: "
+cfgs = [(1, 6, 17), (6, 6, 17), (6, 2, 129), (6, 3, 129), (6, 3, 65), (6, 4, 65), (6, 4, 17), (4, 3, 129), (1, 6, 17)]
+if len(sys.argv) > 2:
+    cfgs = [tuple(int(x) for x in c.split(":")) for c in sys.argv[2].split(",")]
+for pf, mn, dl in cfgs:
+    eng.set_tuning(attn_prefetch=pf, attn_prefetch_min=mn, attn_prefetch_delay=dl)
+    line = f"prefetch {pf - 1}/8 from {mn} chunks, delay {dl - 1} x 64 cycles: "
     outs = []
     for ids in prompts:
         eng.generate(ids, 16, mode="kangaroo")
