@@ -101,10 +101,10 @@ def cpu_baseline(shape, L, base_sd_gpu, adapter_sd_gpu, steps, thr, model, n_pro
 
 def main_tp(a, shape, L, ds, hs, tdt, dev, dist, rank, world):
     """--tp N: every group of N ranks holds ONE model whose remaining layers are split N ways (kangaroo_amd/tp.py);
-    the draft stack is replicated.  The loop is driven pass by pass (the partial sums of every layer cross the
-    process group between kernel launches), so this path is launch-bound: it exists to run the >= 33B-class
-    configuration across GPUs with exact rank-order sums, not to set a speed record.  Groups decode disjoint
-    prompts; the job's tokens are counted once per group."""
+    the draft stack is replicated.  The loop is driven pass by pass from the host; a pass over the split layers (its
+    kernels and the exchanges of the partial sums between them) is one captured graph per row count, replayed at
+    changing positions (--tp-no-graphs launches it kernel by kernel).  Groups decode disjoint prompts; the job's
+    tokens are counted once per group."""
     from kangaroo_amd.inference import kangaroo_forward_stepwise
     from kangaroo_amd.tp import DistGroup, LocalGroup, TPKangarooModel
     if a.tp_local:
@@ -116,7 +116,7 @@ def main_tp(a, shape, L, ds, hs, tdt, dev, dist, rank, world):
         pgs = [dist.new_group(list(range(g * a.tp, (g + 1) * a.tp))) for g in range(n_groups)]
         group = DistGroup(pgs[gidx])
     base_sd, adapter_sd = synth_state_dicts(shape, L, seed=0, dtype=tdt, recipe=Recipe.agreeable(ds, hs), device=dev)
-    model = TPKangarooModel(shape, base_sd, adapter_sd, tdt, L, group, device=dev)
+    model = TPKangarooModel(shape, base_sd, adapter_sd, tdt, L, group, device=dev, graphs=not a.tp_no_graphs)
     del base_sd, adapter_sd
     torch.cuda.empty_cache()
     K, W = a.steps, a.warmup
@@ -168,12 +168,12 @@ def main_tp(a, shape, L, ds, hs, tdt, dev, dist, rank, world):
            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
            "config": {"workload": f"{a.model} shape {'fp16' if a.dtype == 'f16' else 'bf16'} Kangaroo exitlayer={L} steps={a.spec_steps} thr={a.threshold} greedy, "
                                   f"synthetic prompts <= 256 tokens, max_new_tokens={new}, remaining layers tensor-parallel x{a.tp} "
-                                  f"({'all ranks rehearsed on one GPU' if a.tp_local else 'RCCL all_gather + rank-order sum'}), pass-by-pass loop",
+                                  f"({'all ranks rehearsed on one GPU' if a.tp_local else 'RCCL all_gather + rank-order sum'}), pass-by-pass loop, {'one captured graph per pass' if not a.tp_no_graphs else 'kernel-by-kernel launches'}",
                       "prompts_per_group": K, "parallelism": f"tp{a.tp} x {n_groups} group(s)"},
            "mean_accept": sum(acc) / max(1, len(acc)),
            "vanilla_tokens_per_s_rank0": sum(v[1] for v in van) / tv, "speedup_vs_vanilla": (new_tokens / elapsed) / (sum(v[1] for v in van) / tv),
            "lossless": f"{agree}/{len(timed)} prompts token-identical to plain greedy decoding over the same tensor-parallel kernels",
-           "roofline": {"bound": "hbm", "kernel": "kg_linear_kernel<GEMV, RMSNorm, SiLU*mul> (gate/up projection of a replicated draft layer; the loop itself is launch-bound)",
+           "roofline": {"bound": "hbm", "kernel": "kg_linear_kernel<GEMV, RMSNorm, SiLU*mul> (gate/up projection of a replicated draft layer)",
                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                         "us_per_launch": us, "algorithmic_bytes_per_launch": wbytes},
            "cpu_baseline": None}
@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--tp", type=int, default=1, help="tensor-parallel degree of the remaining-layer verify pass (the >= 33B-class configuration): "
                     "ranks form groups of this many GPUs, one replica per group")
     ap.add_argument("--tp-local", action="store_true", help="rehearse all --tp ranks of a group on ONE GPU, shard after shard (no process group)")
+    ap.add_argument("--tp-no-graphs", action="store_true", help="launch the tensor-parallel pass kernel by kernel instead of replaying one captured graph per row count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-prompts", type=int, default=4, help="prompts of the bounded CPU-baseline sample (32 tokens in, 32 out each)")
     ap.add_argument("--no-vanilla", action="store_true")

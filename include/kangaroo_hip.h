@@ -111,6 +111,12 @@ int kg_linear(int dtype, const void* w_packed, int N, int K, const void* x, int 
 /* 256 B, plus room for the normalised rows of a pass of more than 16 rows */
 size_t kg_linear_scratch_bytes(int n_rows, int K);
 
+/* pos0 of kg_qkv_rope_append / kg_attention: the first position is not in the call but in device memory, the int32
+ * at scratch + 128, read when the pass runs.  For callers that capture a pass into a graph once and replay it at
+ * changing positions (they update that int between replays); a value outside [0, t_max - n_rows] turns the pass
+ * into a no-op. */
+#define KG_POS_IN_SCRATCH (-2)
+
 /* Fused RMSNorm + QKV projection + RoPE + in-place KV append for n_rows (<= 128) rows at
  * positions pos0.. (adapter.py:170-189 with the cache growing by torch.cat there).
  * K cache [Hkv][t_max][hd]; V cache [Hkv][t_max][hd] (v_transposed 0) or [Hkv][hd][t_max]

@@ -16,6 +16,34 @@ int kg_launch_set_dyn(KgDyn* dyn, int active, int n_rows, int pos0, hipStream_t 
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// The same parameters with the first position read on the device (a pass inside a captured graph whose position
+// changes from replay to replay).  A position outside [0, t_max - n_rows] switches the pass off instead of letting its
+// cache writes leave the cache.
+__global__ void kg_set_dyn_from_kernel(KgDyn* dyn, int n_rows, const int* pos0_p, int t_max) {
+    const int i = threadIdx.x, pos0 = *pos0_p;
+    const int ok = (pos0 >= 0 && pos0 + n_rows <= t_max) ? 1 : 0;
+    if (i == 0) { dyn->active = ok; dyn->n_rows = n_rows; }
+    if (i < KG_MAX_ROWS) dyn->pos[i] = ok ? pos0 + i : 0;
+}
+int kg_launch_set_dyn_from(KgDyn* dyn, int n_rows, const int* pos0_p, int t_max, hipStream_t st) {
+    if (n_rows < 0 || n_rows > KG_GEMM_ROWS || !pos0_p) return -1;
+    hipLaunchKernelGGL(kg_set_dyn_from_kernel, dim3(1), dim3(64), 0, st, dyn, n_rows, pos0_p, t_max);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// n words of zeros, as a kernel: inside a captured graph a memset node was seen to overlap the kernel node that
+// follows it (arrival counters wiped while blocks were counting), kernel nodes keep their order.
+__global__ void kg_zero_u32_kernel(unsigned* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+int kg_launch_zero_u32(unsigned* p, int n, hipStream_t st) {
+    if (!p || n < 0) return -1;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(kg_zero_u32_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, n);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // out[m][:] = embed[tokens[pos[0] + m]][:]   (16-bit elements, d % 8 == 0; rows of a pass sit at consecutive positions)
 __global__ void kg_embed_kernel(const KgDyn* dyn, const int* tokens, const kg_u4* embed, int d8, kg_u4* out, int out_stride8) {
     if (dyn->active == 0) return;

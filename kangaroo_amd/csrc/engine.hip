@@ -1068,10 +1068,12 @@ extern "C" int kg_qkv_rope_append(int dtype, const void* wqkv_packed, int d, int
     if (!wqkv_packed || !x || !norm_w || !rope_cos || !rope_sin || !q_out || !k_cache || !v_cache || !scratch) return fail(-1, "null argument");
     const int min_rows = (n_rows == -1) ? 2 : 1;          // -1: one row in a multi-row pass's arithmetic (see kg_linear)
     if (n_rows == -1) n_rows = 1;
-    if (n_rows < 1 || n_rows > KG_GEMM_ROWS || pos0 < 0 || pos0 + n_rows > t_max) return fail(-1, "bad rows / positions");
+    const bool pos_dev = (pos0 == KG_POS_IN_SCRATCH);       // the first position is the int at scratch + 128, read on the device
+    if (n_rows < 1 || n_rows > KG_GEMM_ROWS || (!pos_dev && (pos0 < 0 || pos0 + n_rows > t_max))) return fail(-1, "bad rows / positions");
     hipStream_t st = (hipStream_t)stream;
     KgDyn* dyn = (KgDyn*)scratch;
-    KG_TRY(kg_launch_set_dyn(dyn, 1, n_rows, pos0, st));
+    if (pos_dev) KG_TRY(kg_launch_set_dyn_from(dyn, n_rows, (const int*)((const char*)scratch + 128), t_max, st));
+    else KG_TRY(kg_launch_set_dyn(dyn, 1, n_rows, pos0, st));
     const int qd = n_heads * head_dim, kvd = n_kv_heads * head_dim;
     KgLinArgs a = lin_base(dyn, wqkv_packed, qd + 2 * kvd, d, x, d);
     a.norm_w = norm_w; a.eps = eps; a.q_out = q_out; a.k_cache = k_cache; a.v_cache = v_cache;
@@ -1097,10 +1099,12 @@ extern "C" int kg_attention(int dtype, const void* q, int n_rows, int pos0, cons
     g_err.clear();
     kg_init_once();
     if (!q || !k_cache || !v_cache || !out || !scratch) return fail(-1, "null argument");
-    if (n_rows < 1 || n_rows > (v_transposed ? KG_GEMM_ROWS : KG_MAX_ROWS) || pos0 < 0 || pos0 + n_rows > t_max || nsplit < 1 || nsplit > 32) return fail(-1, "bad argument");
+    const bool pos_dev = (pos0 == KG_POS_IN_SCRATCH);
+    if (n_rows < 1 || n_rows > (v_transposed ? KG_GEMM_ROWS : KG_MAX_ROWS) || (!pos_dev && (pos0 < 0 || pos0 + n_rows > t_max)) || nsplit < 1 || nsplit > 32) return fail(-1, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     KgDyn* dyn = (KgDyn*)scratch;
-    KG_TRY(kg_launch_set_dyn(dyn, 1, n_rows, pos0, st));
+    if (pos_dev) KG_TRY(kg_launch_set_dyn_from(dyn, n_rows, (const int*)((const char*)scratch + 128), t_max, st));
+    else KG_TRY(kg_launch_set_dyn(dyn, 1, n_rows, pos0, st));
     KgAttnArgs a;
     memset(&a, 0, sizeof(a));
     a.dyn = dyn; a.q = q; a.k_cache = k_cache; a.v_cache = v_cache; a.H = n_heads; a.Hkv = n_kv_heads; a.hd = head_dim; a.t_max = t_max; a.v_transposed = v_transposed ? 1 : 0;
@@ -1108,7 +1112,7 @@ extern "C" int kg_attention(int dtype, const void* q, int n_rows, int pos0, cons
     a.part_o = (float*)((char*)scratch + 256);
     a.part_ml = a.part_o + (size_t)nsplit * KG_GEMM_ROWS * n_heads * head_dim;
     a.counters = (unsigned*)(((uintptr_t)(a.part_ml + (size_t)nsplit * KG_GEMM_ROWS * n_heads * 2) + 255) & ~(uintptr_t)255);
-    KG_CHECK_HIP(hipMemsetAsync(a.counters, 0, (KG_GEMM_ROWS / 16) * (size_t)n_heads * sizeof(unsigned), st));
+    KG_TRY(kg_launch_zero_u32(a.counters, (KG_GEMM_ROWS / 16) * n_heads, st));
     // partial buffers are indexed with max_rows = n_rows, within the KG_GEMM_ROWS-sized scratch
     a.out = out;
     int rc = kg_launch_attn(a, dtype, st);

@@ -84,6 +84,8 @@ int kg_launch_persist(const KgPhase* phases_dev, int n_phases, unsigned* bar, in
 
 // small control / glue kernels
 int kg_launch_set_dyn(KgDyn* dyn, int active, int n_rows, int pos0, hipStream_t st);
+int kg_launch_zero_u32(unsigned* p, int n, hipStream_t st);
+int kg_launch_set_dyn_from(KgDyn* dyn, int n_rows, const int* pos0_p, int t_max, hipStream_t st);
 int kg_launch_embed(const KgDyn* dyn, const int* tokens, const void* embed, int d, void* out, int out_stride, hipStream_t st);
 int kg_launch_rmsnorm(const KgDyn* dyn, const void* x, int x_stride, const void* w, float eps, int K, void* out, int out_stride, int dtype, hipStream_t st);
 int kg_launch_head_finalize(const KgDyn* dyn, const float* head_part, int head_part_stride, int nblocks, int max_rows,

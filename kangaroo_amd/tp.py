@@ -87,8 +87,10 @@ def shard_layer(sd: Dict[str, torch.Tensor], prefix: str, shape: LlamaShape, tp:
 def ordered_sum(parts: torch.Tensor) -> torch.Tensor:
     """[tp, rows, d] fp32 partial sums -> their sum, added in rank order (one fp32 addition per rank, so every
     rank, and a single-GPU rehearsal, gets the same bits)."""
-    acc = parts[0].clone()
-    for r in range(1, parts.shape[0]):
+    if parts.shape[0] == 1:
+        return parts[0].clone()
+    acc = parts[0] + parts[1]                 # elementwise kernels only: inside a captured graph they keep their order
+    for r in range(2, parts.shape[0]):
         acc += parts[r]
     return acc
 
@@ -158,6 +160,8 @@ class TPShard:
         self.nsplit = 16
         self.scratch = torch.zeros(256, dtype=torch.uint8, device=dev)
         self.ascratch = torch.zeros(self.lib.kg_attention_scratch_bytes(self.hl, hd, self.nsplit), dtype=torch.uint8, device=dev)
+        # the int32 at byte 128 of a scratch block: where a captured pass reads its first position (POS_IN_SCRATCH)
+        self.pos_slots = [self.scratch[128:132].view(torch.int32), self.ascratch[128:132].view(torch.int32)]
 
     def _p(self, t):
         return C.c_void_p(t.data_ptr())
@@ -203,7 +207,8 @@ class TPShard:
 
 def tp_forward(shards: Sequence[TPShard], group, x: torch.Tensor, pos0: int, trace: Optional[list] = None) -> torch.Tensor:
     """Layers [L, N) on rows x [rows <= 16, d] at positions pos0.. .  `shards`: this process's shard (one entry,
-    with a DistGroup) or every rank's (LocalGroup).  Returns the hidden rows, identical on every rank."""
+    with a DistGroup) or every rank's (LocalGroup).  Returns the hidden rows, identical on every rank.
+    pos0 == POS_IN_SCRATCH: the kernels read the first position from the shards' position slots (TPGraphs)."""
     h = x.contiguous()
     for i in range(len(shards[0].layers)):
         parts = group.all_partials([s.attn_partial(i, h, pos0) for s in shards])
@@ -217,13 +222,81 @@ def tp_forward(shards: Sequence[TPShard], group, x: torch.Tensor, pos0: int, tra
     return h
 
 
+POS_IN_SCRATCH = -2     # KG_POS_IN_SCRATCH of include/kangaroo_hip.h
+
+
+class TPGraphs:
+    """tp_forward captured once per row count and replayed: ~9 kernel launches and two exchanges per layer and shard
+    leave the host as one graph launch, so the verify pass is no longer bound by the launch rate of the interpreter.
+    The first position of a pass lives in device memory (one int32 per process, copied into every shard's
+    position slots by the graph itself) and is the only thing that changes between replays besides the input rows.
+    With a DistGroup the all-gathers are captured with the kernels (RCCL supports stream capture); every rank
+    must capture and replay the same row counts in the same order."""
+
+    def __init__(self, shards: Sequence[TPShard], group, dtype: torch.dtype, max_rows: int = 16):
+        self.shards, self.group, self.dtype, self.max_rows = list(shards), group, dtype, max_rows
+        dev = self.shards[0].device
+        self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.graphs: Dict[int, tuple] = {}
+        self.pool = None
+
+    def _body(self, x: torch.Tensor) -> torch.Tensor:
+        for s in self.shards:
+            for slot in s.pos_slots:
+                torch.add(self.pos, 0, out=slot)      # a kernel, not a copy node (see kg_attention's counters)
+        return tp_forward(self.shards, self.group, x, POS_IN_SCRATCH)
+
+    def _capture(self, x: torch.Tensor, pos0: int):
+        # Captured on the pass that first needs this row count, with its own rows and position: the eager run that
+        # precedes the capture then writes this pass's true K/V rows (a dummy pass would overwrite cache rows in use),
+        # and the replay that follows computes the same values again.
+        n = x.shape[0]
+        xs = x.clone()
+        self.pos.fill_(pos0)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                 # one eager run on a side stream first, as graph capture asks
+            self._body(xs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.pool):
+            out = self._body(xs)
+        if self.pool is None:
+            self.pool = g.pool()
+        self.graphs[n] = (g, xs, out)
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor, pos0: int) -> torch.Tensor:
+        n = x.shape[0]
+        if n > self.max_rows:
+            return tp_forward(self.shards, self.group, x, pos0)
+        if pos0 < 0 or pos0 + n > self.shards[0].t_max:
+            raise ValueError("positions outside the cache")
+        if n not in self.graphs:
+            try:
+                self._capture(x, pos0)
+            except RuntimeError as e:                 # e.g. a process-group backend that cannot be captured
+                import warnings
+                warnings.warn(f"tensor-parallel pass of {n} rows could not be captured ({e}); launching it kernel by kernel")
+                self.max_rows = 0
+                torch.cuda.synchronize()
+                return tp_forward(self.shards, self.group, x, pos0)
+        g, xs, out = self.graphs[n]
+        xs.copy_(x)
+        self.pos.fill_(pos0)                          # the value travels with the fill kernel: later calls cannot overtake it
+        g.replay()
+        return out.clone()
+
+
 class TPEarlyExitLlamaForCausalLM(EarlyExitLlamaForCausalLM):
     """EarlyExitLlamaForCausalLM (kangaroo/earlyexit.py:6-71) whose remaining layers are tensor-parallel shards.
     The engine holds the replicated draft stack only (exit_layer == its layer count)."""
 
-    def __init__(self, engine: KangarooEngine, shards: Sequence[TPShard], group, EARLY_STOP_LAYER: int, n_layers: int):
+    def __init__(self, engine: KangarooEngine, shards: Sequence[TPShard], group, EARLY_STOP_LAYER: int, n_layers: int, graphs: bool = True):
         super().__init__(engine, EARLY_STOP_LAYER)
         self.shards, self.group, self.n_layers = list(shards), group, n_layers
+        self.graphs = TPGraphs(self.shards, group, engine.dtype) if graphs else None
 
     def _views(self, layer: int, length: int):
         if layer < self.early_exit_layer:
@@ -231,7 +304,10 @@ class TPEarlyExitLlamaForCausalLM(EarlyExitLlamaForCausalLM):
         return self.shards[0].kv_views(layer - self.early_exit_layer, length)
 
     def _deep(self, x: torch.Tensor, pos0: int) -> torch.Tensor:
-        return tp_forward(self.shards, self.group, x.to(self.engine.dtype), pos0)
+        x = x.to(self.engine.dtype)
+        if self.graphs is not None:
+            return self.graphs(x, pos0)
+        return tp_forward(self.shards, self.group, x, pos0)
 
     @torch.no_grad()
     def __call__(self, input_ids, position_ids=None, output_hidden_states=True, logits_rows="all"):
@@ -279,7 +355,7 @@ class TPKangarooModel:
     rehearse every rank on one GPU."""
 
     def __init__(self, shape: LlamaShape, base_sd, adapter_sd, dtype, EARLY_STOP_LAYER: int, group, rank: Optional[int] = None,
-                 max_length: int = 2048, device="cuda"):
+                 max_length: int = 2048, device="cuda", graphs: bool = True):
         from .adapter import AdapterModel
         from .kangaroo_model import HeadModel
         L = EARLY_STOP_LAYER
@@ -287,7 +363,7 @@ class TPKangarooModel:
         self.engine = KangarooEngine(draft_shape, base_sd, adapter_sd, exit_layer=L, dtype=dtype, device=device, max_length=max_length)
         ranks = range(group.tp) if isinstance(group, LocalGroup) else [group.rank if rank is None else rank]
         self.shards = [TPShard(shape, base_sd, L, group.tp, r, dtype, device, max_length) for r in ranks]
-        self.base_model = TPEarlyExitLlamaForCausalLM(self.engine, self.shards, group, L, shape.num_hidden_layers)
+        self.base_model = TPEarlyExitLlamaForCausalLM(self.engine, self.shards, group, L, shape.num_hidden_layers, graphs=graphs)
         self.adapter_model = AdapterModel(self.engine)
         self.head_model = HeadModel(self.engine)
 

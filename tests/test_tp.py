@@ -178,3 +178,34 @@ def test_tp_verify_pass_on_one_device(name, n_layers, tp, dtype, tol):
     assert van[0][0][:m] == out[0][0][:m]
     del model, plain, om
     torch.cuda.empty_cache()
+
+
+@gpu
+def test_captured_tp_pass_equals_the_launch_by_launch_pass():
+    """TPGraphs replays one captured pass per row count at changing positions (the first position is read on the
+    device): hidden rows, K/V caches and the decode loop's tokens equal the launch-by-launch path bit for bit."""
+    from kangaroo_amd.tp import TPKangarooModel
+    shape = LlamaShape(256, 4, 8, 8, 768, 1000)
+    L, tp, dtype = 2, 2, torch.float16
+    base, adapter = synth_state_dicts(shape, L, seed=73, dtype=dtype, recipe=Recipe.agreeable(0.3, 8.0), device="cuda")
+    mg = TPKangarooModel(shape, base, adapter, dtype, L, LocalGroup(tp), graphs=True)
+    me = TPKangarooModel(shape, base, adapter, dtype, L, LocalGroup(tp), graphs=False)
+    assert mg.base_model.graphs is not None and me.base_model.graphs is None
+    g = torch.Generator().manual_seed(11)
+    pos = 0
+    for step in range(60):                             # every row count but the first use of each is a pure replay; the
+        n = (16, 5, 1, 7)[step % 4]                    # context grows past two key chunks (128 keys each at this cache size),
+        x = torch.randn(n, shape.hidden_size, generator=g).to(dtype).cuda()     # where attention blocks meet at counters
+        hg = mg.base_model._deep(x, pos)
+        he = me.base_model._deep(x, pos)
+        assert torch.equal(hg, he), (step, n, pos)
+        pos += n
+    assert pos > 400 and sorted(mg.base_model.graphs.graphs) == [1, 5, 7, 16]
+    for sg, se in zip(mg.shards, me.shards):
+        assert torch.equal(sg.k_cache, se.k_cache) and torch.equal(sg.v_cache, se.v_cache)
+    with pytest.raises(ValueError):
+        mg.base_model._deep(torch.zeros(5, shape.hidden_size, dtype=dtype, device="cuda"), mg.shards[0].t_max - 2)
+    ids = torch.randint(3, shape.vocab_size, (1, 21), generator=g)          # 21 rows: the prompt pass runs 16 + 5
+    og = ko.kangaroo_forward(ids.cuda(), mg, 2, 40, EARLY_STOP_LAYER=L)
+    oe = ko.kangaroo_forward(ids.cuda(), me, 2, 40, EARLY_STOP_LAYER=L)
+    assert og[0] == oe[0] and og[3] == oe[3]
