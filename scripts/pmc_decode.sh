@@ -1,6 +1,7 @@
 #!/bin/bash
 # Hardware counters per kernel over a short 7B decode (one rocprofv3 run per counter group).
 # usage: pmc_decode.sh <out.txt> "<counters of pass 1>" "<counters of pass 2>" ...
+# PMC_ARGS: further arguments of scripts/bench_ops.py (e.g. "--plen 1000 attn_prefetch=1")
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 out=$1
@@ -10,7 +11,7 @@ i=0
 for c in "$@"; do
   i=$((i + 1))
   d=gpurun_out/pmc_pass$i
-  timeout -s KILL 240 rocprofv3 --pmc $c -d $d -o p --output-format csv -- python3 scripts/bench_ops.py vicuna-7b --decode --short > $d.log 2>&1 || { echo "pass '$c' failed" >> "$out"; tail -3 $d.log >> "$out"; exit 1; }
+  timeout -s KILL 240 rocprofv3 --pmc $c -d $d -o p --output-format csv -- python3 scripts/bench_ops.py vicuna-7b --decode --short $PMC_ARGS > $d.log 2>&1 || { echo "pass '$c' failed" >> "$out"; tail -3 $d.log >> "$out"; exit 1; }
   f=$(ls $d/*counter_collection.csv 2>/dev/null || ls $d/*/*counter_collection.csv)
   echo "== pass: $c" >> "$out"
   python3 - "$f" >> "$out" <<'PY'
