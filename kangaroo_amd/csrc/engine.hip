@@ -631,7 +631,9 @@ static int build_program(kg_session* s, int which, const KgDyn* dyn, int max_row
 }
 
 static int run_program(kg_session* s, int which, hipStream_t st) {
-    KG_CHECK_HIP(hipMemsetAsync(s->bar, 0, 256 * sizeof(unsigned), st));
+    // cleared by a kernel: this runs inside the captured round graph, where a memset node does not reliably finish
+    // before the kernel node that follows it
+    KG_TRY(kg_launch_zero_u32(s->bar, 256, st));
     return kg_launch_persist(s->prog_dev[which], s->prog_n[which], s->bar, s->sh.dtype, g_ncu, s->prog_smem[which], s->tlog, st);
 }
 
