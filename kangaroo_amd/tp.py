@@ -88,7 +88,7 @@ def ordered_sum(parts: torch.Tensor) -> torch.Tensor:
     """[tp, rows, d] fp32 partial sums -> their sum, added in rank order (one fp32 addition per rank, so every
     rank, and a single-GPU rehearsal, gets the same bits)."""
     if parts.shape[0] == 1:
-        return parts[0].clone()
+        return parts[0] * 1                   # exact, and a kernel rather than a copy
     acc = parts[0] + parts[1]                 # elementwise kernels only: inside a captured graph they keep their order
     for r in range(2, parts.shape[0]):
         acc += parts[r]
