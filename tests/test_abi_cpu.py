@@ -215,3 +215,11 @@ def test_speed_report_from_answer_files(tmp_path):
     assert abs(r["tokens_per_second"] - (200 + 400) / 2) < 1e-9 and abs(r["tokens_per_second_baseline"] - (100 + 100) / 2) < 1e-9
     assert abs(r["speedup"] - 3.0) < 1e-9 and abs(r["mean_accept"] - 2.0) < 1e-9
     assert speed(str(k), str(b), task="qa")["questions"] == 1
+
+
+def test_constants_of_the_header_match_the_bindings():
+    """Values the Python side passes by number are the header's."""
+    src = open(os.path.join(ROOT, "include", "kangaroo_hip.h")).read()
+    from kangaroo_amd import tp
+    m = re.search(r"#define\s+KG_POS_IN_SCRATCH\s+\((-?\d+)\)", src)
+    assert m and int(m.group(1)) == tp.POS_IN_SCRATCH
