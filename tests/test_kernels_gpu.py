@@ -185,6 +185,26 @@ def test_qkv_rope_attention(dtype, code, H, Hkv, hd, rows, pos0):
         _lib.check(lib.kg_attention(code, vp(q), rows, pos0, vp(kc), vp(vc), H, Hkv, hd, t_max, vt, nsplit, vp(o), vp(ascr), stream()), "kg_attention")
         torch.cuda.synchronize()
         assert rel_err(o, attn_ref) < (1e-2 if dtype == torch.float16 else 5e-2), nsplit
+    # first position read on the device (the int32 at scratch + 128): the same bits as with the position in the call,
+    # and a position that would leave the cache turns the pass into a no-op
+    POS_IN_SCRATCH = -2
+    kc2, vc2, q2 = kc.clone(), vc.clone(), torch.empty_like(q)
+    kc2[:, pos0:] = 0
+    (vc2[:, :, pos0:] if vt else vc2[:, pos0:]).zero_()
+    slot, aslot = scratch[128:132].view(torch.int32), ascr[128:132].view(torch.int32)
+    for first, live in ((pos0, True), (t_max - rows + 1, False)):
+        slot.fill_(first); aslot.fill_(first)
+        before = (kc2.clone(), vc2.clone())
+        _lib.check(lib.kg_qkv_rope_append(code, vp(wqkv_d), d, H, Hkv, hd, vp(x_d), rows, POS_IN_SCRATCH,
+                                          vp(nw_d), 1e-6, vp(cos), vp(sin), vp(q2), vp(kc2), vp(vc2), t_max, vt, vp(scratch), 0, 0, stream()),
+                   "kg_qkv_rope_append")
+        o2 = torch.full((rows, H * hd), float("nan"), dtype=dtype, device=DEV)
+        _lib.check(lib.kg_attention(code, vp(q2), rows, POS_IN_SCRATCH, vp(kc2), vp(vc2), H, Hkv, hd, t_max, vt, nsplit, vp(o2), vp(ascr), stream()), "kg_attention")
+        torch.cuda.synchronize()
+        if live:
+            assert torch.equal(q2, q) and torch.equal(kc2, kc) and torch.equal(vc2, vc) and torch.equal(o2, o)
+        else:
+            assert torch.equal(kc2, before[0]) and torch.equal(vc2, before[1]) and bool(torch.isnan(o2.float()).all())
 
 
 @pytest.mark.parametrize("dtype,code", DTYPES, ids=["f16", "bf16"])
