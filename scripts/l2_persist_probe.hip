@@ -52,9 +52,11 @@ int main(int argc, char** argv) {
     const size_t per16 = per_xcd / 16;
     int* x0_dev; CK(hipMalloc(&x0_dev, 256)); CK(hipMemset(x0_dev, 0, 256));
     const int use_graph = argc > 2 ? atoi(argv[2]) : 0, predict = argc > 3 ? atoi(argv[3]) : 0;
-    printf("graph %d predict %d\n", use_graph, predict);
+    // the stream between A and B (mode 2): MiB per XCD, plain or non-temporal loads
+    const size_t mid_mib = argc > 4 ? atol(argv[4]) : 8; const int mid_nt = argc > 5 ? atoi(argv[5]) : 0;
+    printf("graph %d predict %d, stream between A and B: %zu MiB per XCD, %s loads\n", use_graph, predict, mid_mib, mid_nt ? "nt" : "plain");
     for (int nt = 0; nt < 2; ++nt)
-    for (int mode = 0; mode < 3; ++mode) {         // 0: B reads what A read; 1: B reads an untouched region; 2: a 64 MiB stream between A and B
+    for (int mode = 0; mode < 3; ++mode) {         // 0: B reads what A read; 1: B reads an untouched region; 2: a stream between A and B
         float tot = 0; double kspan = 0; const int reps = 20;
         for (int r = 0; r < reps + 2; ++r) {
             const size_t a_off = ((size_t)(r % 16) * 8 * per_xcd * 2) / 16;          // a fresh region per repetition (beyond the 256 MiB cache after 16 reps it recycles; fine for L2)
@@ -65,7 +67,7 @@ int main(int argc, char** argv) {
             hipLaunchKernelGGL(k_read, dim3(nb), dim3(512), 0, st, (const u4*)pool, per16, a_off, tick, sink, stamps, 0, 0, x0_dev);
             if (mode == 2) {
                 hipLaunchKernelGGL(k_zero, dim3(1), dim3(256), 0, st, tick, 256);
-                hipLaunchKernelGGL(k_read, dim3(nb), dim3(512), 0, st, (const u4*)(pool + ((size_t)1 << 30)), (size_t)(8 << 20) / 16, 0, tick, sink, stamps, 0, 0, x0_dev);
+                hipLaunchKernelGGL(k_read, dim3(nb), dim3(512), 0, st, (const u4*)(pool + ((size_t)1 << 30)), (mid_mib << 20) / 16, 0, tick, sink, stamps, mid_nt, 0, x0_dev);
             }
             hipLaunchKernelGGL(k_zero, dim3(1), dim3(256), 0, st, tick, 256);
             if (!use_graph) CK(hipEventRecord(e0, st));
@@ -86,7 +88,7 @@ int main(int argc, char** argv) {
             for (int b = 0; b < nb; ++b) { if (h[2 * b] < lo) lo = h[2 * b]; if (h[2 * b + 1] > hi) hi = h[2 * b + 1]; }
             if (r >= 2) { tot += ms; kspan += (double)(hi - lo) * 0.01; }
         }
-        const char* names[3] = {"B re-reads A's regions (same XCD)", "B reads untouched regions", "B re-reads A's regions after a 64 MiB stream"};
+        const char* names[3] = {"B re-reads A's regions (same XCD)", "B reads untouched regions", "B re-reads A's regions after the stream"};
         printf("%5zu KiB per XCD, %s loads, %-46s: events %.2f us, first entry -> last exit %.2f us  (%.0f GB/s)\n", per_xcd >> 10, nt ? "nt" : "plain", names[mode],
                tot / reps * 1e3, kspan / reps, 8.0 * per_xcd / (kspan / reps * 1e-6) / 1e9);
     }
