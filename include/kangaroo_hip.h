@@ -195,7 +195,7 @@ int kg_session_get(kg_session* s, const char* key);
  * block working on different chunks at once): geometry only, results do not change;
  * "attn_prefetch" (1: off, 1 + n: attention blocks whose chunks hold no keys yet read the first n/8 of every
  * o_proj row group into the L2 their XCD shares with the o_proj blocks that follow; default: the share that
- * comes to about 21 MB of o_proj, 6 at the 7B shape),
+ * comes to about 24 MB of o_proj, 7 at the 7B shape),
  * "attn_prefetch_min" (chunks in use from which they do so; default 6) and "attn_prefetch_delay" (1 + cycles / 64
  * they wait first; default 17): timing only, the values read are discarded;
  * "<mode>_waves" and "<mode>_blocks_per_cu" for all linear ops of a mode, or "<mode>.<op>.waves" /

@@ -201,9 +201,9 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     s->vanilla_gemv = 0;
     s->attn_teams = 1;
     s->attn_prefetch_min = 6; s->attn_prefetch_delay = 16;
-    {   // about 21 MB of o_proj (2.6 MB per XCD, whose L2 holds 4 MB) in eighths of a row group
+    {   // about 24 MB of o_proj (3 MB per XCD, whose L2 holds 4 MB) in eighths of a row group (measured: 5/8 .. 8/8 alike at 7B, 4/8 .. 5/8 best at 13B, 2/8 at the 33B shape)
         const double ob = 2.0 * shape->hidden_size * s->q_dim;
-        int e = (int)(8.0 * 21.0e6 / ob + 0.5);
+        int e = (int)(8.0 * 24.0e6 / ob + 0.5);
         s->attn_prefetch = e < 1 ? 1 : (e > 8 ? 8 : e);
     }
     s->attn_blocks = 16;                         // one chunk per block: long contexts need many CUs pulling K/V (one CU sustains only ~60 GB/s)
