@@ -9,6 +9,9 @@ max_new_tokens=1024, random-init weights with a recipe calibrated so the mean ac
 length is near the reference's recorded 2.05.  For N>1 (launched by
 torch.distributed.run, one rank per GPU) every rank holds a full replica and decodes
 its own K prompts: independent bsz=1 streams, no data-path collective ("weak" scaling).
+Run without a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) the script starts the N
+ranks itself, one fresh child process per GPU, relays rank 0's line and exits non-zero if any rank
+did; this mirrors the reference's harness, which spawns its own workers (evaluation/eval.py:38-68).
 
 Rank 0 prints ONE JSON line: whole-job decode tokens/s (prefill inside the timed
 region, as the reference's harness times it), speed-up over plain greedy decoding on
@@ -97,6 +100,75 @@ def cpu_baseline(shape, L, base_sd_gpu, adapter_sd_gpu, steps, thr, model, n_pro
             "identical_tokens_vs_gpu": f"{same_tokens}/{cmp_tokens} new tokens before the first difference, summed over the prompts",
             "first_difference": diffs,
             "all_differences_within_tol": all(d["kind"] == "none" or d["within_tol"] for d in diffs)}
+
+
+def self_launch(n_ranks, argv):
+    """Start n_ranks copies of this script, rank r on GPU r, and wait for them (the parent never touches a GPU and is
+    not replaced by a child: fresh processes, rendezvous on 127.0.0.1 at a free port).  Rank 0's stdout is relayed;
+    the exit status is the first non-zero status of a rank, whose peers are then stopped instead of left waiting in
+    a collective."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            for p in procs:                 # exactly the children started above
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    if out0 and out0[0]:
+        sys.stdout.write(out0[0].decode(errors="replace"))
+        sys.stdout.flush()
+    return rc
+
+
+def launch_check(a, rank, world):
+    """--launch-check: what a rank does around the decode (process group, SUM of tokens / MAX of time over the ranks,
+    one line from rank 0) with stand-in numbers instead of a decode; needs no GPU (gloo)."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(os.environ.get("KG_BENCH_BACKEND", "gloo"), rank=rank, world_size=world)
+    tot = torch.tensor([100.0 + rank, 1.0 + rank], dtype=torch.float64)
+    ranks = [None] * world
+    if world > 1:
+        tmax = tot.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_gather_object(ranks, (rank, int(os.environ.get("LOCAL_RANK", "0"))))
+        tot[1] = tmax[1]
+    else:
+        ranks = [(0, 0)]
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "tp": a.tp, "ranks": ranks, "tokens": float(tot[0]), "t_job": float(tot[1])}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main_tp(a, shape, L, ds, hs, tdt, dev, dist, rank, world):
@@ -202,7 +274,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-prompts", type=int, default=4, help="prompts of the bounded CPU-baseline sample (32 tokens in, 32 out each)")
     ap.add_argument("--no-vanilla", action="store_true")
+    ap.add_argument("--launch-check", action="store_true", help="start the ranks, form the process group, aggregate stand-in numbers and print one line: "
+                    "the launch path without a decode (runs without a GPU under KG_BENCH_BACKEND=gloo)")
     a = ap.parse_args()
+
+    # ranks this job needs: --gpus N replicas, or whole tensor-parallel groups
+    want = a.gpus if (a.tp <= 1 or a.tp_local) else max(a.gpus, a.tp)
+    if a.tp > 1 and not a.tp_local and want % a.tp:
+        sys.exit(f"bench.py: --gpus {a.gpus} is not a multiple of --tp {a.tp}")
+    if "WORLD_SIZE" not in os.environ and want > 1:
+        sys.exit(self_launch(want, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -217,9 +298,11 @@ def main():
                 time.sleep(45)
                 print(f"[bench] {a.model}: running, {time.time() - t_start:.0f} s", file=sys.stderr, flush=True)
         threading.Thread(target=_heartbeat, daemon=True).start()
-    if a.gpus != world:
-        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE is {world}: for N > 1 launch one rank per GPU with "
-                 f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...`")
+    if want != world:
+        sys.exit(f"bench.py: --gpus {a.gpus} --tp {a.tp} needs {want} rank(s) but WORLD_SIZE is {world}: run it without a launcher "
+                 f"(it starts its own ranks) or with `python -m torch.distributed.run --nnodes=1 --nproc-per-node {want} --master-addr 127.0.0.1 bench.py ...`")
+    if a.launch_check:
+        return launch_check(a, rank, world)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -128,7 +128,12 @@ class AdapterTrainer:
 
     def __init__(self, shape: LlamaShape, adapter_sd: Dict[str, torch.Tensor], head_weight: torch.Tensor, dtype=torch.float16,
                  lr: float = 5e-5, betas=(0.9, 0.95), adam_eps: float = 1e-8, weight_decay: float = 1e-2, grad_clip: float = 0.5,
-                 num_warmup_steps: int = 2000, total_steps: int = 800000, loss_scale: Optional[float] = None, device="cuda", group=None):
+                 num_warmup_steps: int = 2000, total_steps: int = 800000, loss_scale: Optional[float] = None, device="cuda", group=None,
+                 grad_accum: int = 8):
+        """grad_accum: the reference builds Accelerator(gradient_accumulation_steps=8) (train.py:8,46-47) and never enters
+        accelerator.accumulate(), so the optimizer steps every iteration while accelerator.backward (train.py:284) divides
+        the loss by 8: the gradients that meet the 0.5 clip and AdamW's eps are those of loss / 8.  With more than one
+        rank accelerate's scheduler wrapper also advances the warm-up schedule once per rank and optimizer step."""
         if dtype not in (torch.float16, torch.bfloat16):
             raise ValueError("dtype must be float16 or bfloat16")
         if not torch.cuda.is_available():
@@ -139,6 +144,7 @@ class AdapterTrainer:
         self.lr, self.betas, self.adam_eps, self.wd, self.clip = lr, betas, adam_eps, weight_decay, grad_clip
         self.warmup, self.total = num_warmup_steps, total_steps
         self.loss_scale = float(loss_scale) if loss_scale is not None else (256.0 if dtype == torch.float16 else 1.0)
+        self.grad_accum = int(grad_accum)
         self.t = 0
         self.sync = GradSync(group)
         self.p = {k: adapter_sd[name].detach().to(self.device, torch.float32).contiguous().clone() for k, name in PARAM_KEYS.items()}
@@ -254,14 +260,15 @@ class AdapterTrainer:
         grads = {"input_layernorm": dg1s, "q_proj": g_q32, "k_proj": g_k32, "v_proj": g_v32, "o_proj": g_o32, "norm": dg2s}
 
         # ---- update (train.py:285-296) ----
-        lr = linear_warmup_lr(self.lr, self.t, self.warmup, self.total)
+        lr = linear_warmup_lr(self.lr, self.t * self.sync.world, self.warmup, self.total)     # AcceleratedScheduler: world steps per update
         self.t += 1
+        inv_scale = 1.0 / (self.loss_scale * self.grad_accum)
         for key, g in grads.items():
             p16 = self.w16.get(key)
-            _lib.check(self.lib.kg_train_adamw(self._p(self.p[key]), self._p(self.m[key]), self._p(self.v[key]), self._p(g), 2, 1.0 / self.loss_scale, self.clip, lr,
+            _lib.check(self.lib.kg_train_adamw(self._p(self.p[key]), self._p(self.m[key]), self._p(self.v[key]), self._p(g), 2, inv_scale, self.clip, lr,
                                                self.betas[0], self.betas[1], self.adam_eps, self.wd, self.t, self.p[key].numel(), self._p(p16), self.dt, self._st()),
                        "kg_train_adamw")
-        self.last_grads = {k: g / self.loss_scale for k, g in grads.items()}          # unscaled, before clipping (tests, logging)
+        self.last_grads = {k: g * inv_scale for k, g in grads.items()}                 # unscaled, before clipping (tests, logging)
         sums = torch.stack([row_loss.sum(), row_acc.sum()] + [((row_rank >= 0) & (row_rank < k)).sum().float() for k in (1, 2, 3)]).tolist()
         # top-k counts as train.py:298-309 accumulates them (the target token = argmax of the target head)
         return {"loss": sums[0] / n_loss, "prob_acc": sums[1] / n_loss, "lr": lr, "tokens": R, "loss_positions": n_loss,
@@ -295,24 +302,48 @@ def list_files(path: str) -> List[str]:
     return out
 
 
+def epoch_batches(n_files: int, bs: int, seed: int, rank: int, world: int) -> List[List[int]]:
+    """File indices of every batch rank `rank` trains on in one epoch: the epoch's shuffled order is cut into batches
+    of `bs` (the last one may be short: DataLoader(drop_last=False), train.py:217), batch i goes to rank i % world, and
+    when the batch count is not a multiple of `world` the order wraps round to its start until it is, as accelerate's
+    sharded loader does (even_batches): EVERY rank runs the same number of steps, which the gradient all-reduce of
+    every step needs.  One rank gets every batch unchanged."""
+    if n_files < 1 or bs < 1:
+        return []
+    g = torch.Generator().manual_seed(seed)
+    order = torch.randperm(n_files, generator=g).tolist()
+    batches = [order[i:i + bs] for i in range(0, n_files, bs)]
+    if world > 1:
+        j = bs - len(batches[-1])                          # fill the short batch, then add whole batches, from the start of the order
+        batches[-1] = batches[-1] + [order[k % n_files] for k in range(j)]
+        while len(batches) % world:
+            batches.append([order[(j + k) % n_files] for k in range(bs)])
+            j += bs
+    return batches[rank::world]
+
+
 def train_epoch(trainer: AdapterTrainer, files: Sequence[str], exit_layer, bs: int, max_len: int = 2048, seed: int = 0,
                 rank: int = 0, world: int = 1, log_steps: int = 20, log=print) -> Dict[str, float]:
     """One epoch of train.py:250-333 over hidden-state files written by the reference's data generation
     (each a torch.save of hidden_state / hidden_state_layer<L> / input_ids / loss_mask): shuffled batches of `bs`
     files, every rank taking its own share of each epoch's order (DataLoader(shuffle=True) + accelerate's
-    sharding), the running totals the reference prints at the end of the epoch."""
-    g = torch.Generator().manual_seed(seed)
-    order = torch.randperm(len(files), generator=g).tolist()[rank::world]
+    sharding, see epoch_batches), the totals the reference prints at the end of the epoch summed over the ranks
+    (accelerator.gather_for_metrics, train.py:322-329)."""
     collate = DataCollatorWithPadding()
     tot = {"loss": 0.0, "batches": 0, "positions": 0, "top1": 0, "top2": 0, "top3": 0}
-    for b0 in range(0, len(order) - bs + 1, bs):
-        feats = [prepare_sample(torch.load(files[i], map_location="cpu", weights_only=True), exit_layer, max_len) for i in order[b0:b0 + bs]]
+    for idx in epoch_batches(len(files), bs, seed, rank, world):
+        feats = [prepare_sample(torch.load(files[i], map_location="cpu", weights_only=True), exit_layer, max_len) for i in idx]
         out = trainer.step(collate(feats))
         tot["loss"] += out["loss"]; tot["batches"] += 1; tot["positions"] += out["loss_positions"]
         for k in (1, 2, 3):
             tot[f"top{k}"] += out[f"top{k}_correct"]
         if rank == 0 and tot["batches"] % log_steps == 1:
             log(f"Step: {tot['batches'] - 1}\tLR: {out['lr']}\tAccept: {out['prob_acc']}\tLoss: {out['loss']}")
+    if world > 1:
+        keys = ("loss", "batches", "positions", "top1", "top2", "top3")
+        t = torch.tensor([float(tot[k]) for k in keys], dtype=torch.float64, device=trainer.device)
+        trainer.sync.dist.all_reduce(t, group=trainer.sync.group)
+        tot = {k: float(v) for k, v in zip(keys, t.tolist())}
     n = max(1, tot["positions"])
     return {"loss": tot["loss"] / max(1, tot["batches"]), "accuracy": tot["top1"] / n, "top2": tot["top2"] / n, "top3": tot["top3"] / n, "batches": tot["batches"]}
 

@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE.  Imports kangaroo.adapter.AdapterModel from /root/reference at run time and runs the
 statements of train.py:258-296 around it on CPU in fp32 (no accelerate: its fp16 autocast needs a GPU; the
-optimizer, scheduler and clipping calls are the ones train.py makes).  Writes DATA only:
+optimizer, scheduler and clipping calls are the ones train.py makes, and the loss is divided by the
+gradient_accumulation_steps of train.py:8,46-47 before backward, as accelerator.backward does).  Writes DATA only:
 tests/golden/train_<case>.npz = inputs, initial parameters, per-step loss / expected acceptance, the first
 step's gradients and the parameters after the last step.
 
@@ -19,6 +20,9 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from oracle.gen_golden import _import_reference          # noqa: E402  (same import stubs as the decode fixtures)
+
+GRAD_ACCUM = 8      # train.py:8,46-47: Accelerator(gradient_accumulation_steps=8); the loop never enters accelerator.accumulate(),
+                    # so every iteration steps the optimizer, and accelerator.backward() divides the loss by 8 first
 
 CASES = [
     # name, hidden, heads, kv heads, vocab, batch lengths, steps, lr, warm-up steps
@@ -100,7 +104,7 @@ def main():
             loss = -torch.sum(torch.sum(loss_mask * plogp, 2)) / loss_mask.sum()
             prob_acc = torch.sum(data["loss_mask"] * prob_acc) / data["loss_mask"].sum()
             lrs.append(optimizer.param_groups[0]["lr"])
-            loss.backward()
+            (loss / GRAD_ACCUM).backward()             # accelerator.backward(loss) (train.py:284) with gradient_accumulation_steps=8
             if i == 0:
                 for k, v in names.items():
                     rec[f"grad0.{k}"] = v.grad.detach().numpy().copy()
@@ -118,6 +122,7 @@ def main():
         rec["prob_acc"] = np.array(accs, dtype=np.float64)
         rec["lr"] = np.array(lrs, dtype=np.float64)
         rec["meta"] = np.array([d, H, Hkv, V, steps, warm], dtype=np.int64)
+        rec["grad_accum"] = np.array([GRAD_ACCUM], dtype=np.int64)
         rec["base_lr"] = np.array([lr], dtype=np.float64)
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
         print(name, "loss", losses, "accept", accs, "lr", lrs)

@@ -106,12 +106,16 @@ class AdamWState:
             params[k].addcdiv_(self.m[k], denom, value=-lr / bc1)
 
 
-def train_step(params: Dict[str, torch.Tensor], opt: AdamWState, head_w, batch, n_heads, n_kv_heads, eps, lr: float, grad_clip: float = 0.5):
-    """One iteration of train.py:258-296 on fp32 tensors; returns (loss, prob_acc, grads before clipping)."""
+def train_step(params: Dict[str, torch.Tensor], opt: AdamWState, head_w, batch, n_heads, n_kv_heads, eps, lr: float, grad_clip: float = 0.5,
+               grad_accum: int = 8):
+    """One iteration of train.py:258-296 on fp32 tensors; returns (loss, prob_acc, grads before clipping).
+    grad_accum: train.py:8,46-47 build Accelerator(gradient_accumulation_steps=8) and accelerator.backward (train.py:284)
+    divides the loss by it, although the loop steps the optimizer every iteration: the gradients that are clipped at
+    0.5 and fed to AdamW are those of loss / 8.  The returned loss is the undivided one (what train.py:281 prints)."""
     leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     predict = adapter_forward(batch["hidden_states_early"], batch["attention_mask"], leaves, n_heads, n_kv_heads, eps)
     loss, prob_acc = loss_and_accept(predict, batch["target"], batch["loss_mask"], head_w)
-    loss.backward()
+    (loss / grad_accum).backward()
     grads = {k: leaves[k].grad.detach().clone() for k in leaves}
     clipped = {k: g.clamp(-grad_clip, grad_clip) for k, g in grads.items()}       # accelerator.clip_grad_value_ (train.py:285)
     opt.step(params, clipped, lr)

@@ -181,6 +181,25 @@ def test_prompt_sharding_two_ranks_gloo(tmp_path):
     assert j["ids"][0] + j["ids"][1] == [p.question_id for p in ps] and len(j["ids"][0]) == 5
 
 
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (WORLD_SIZE unset) starts two rank processes itself, as the
+    reference's harness spawns its workers (evaluation/eval.py:38-68); --launch-check stops short of the decode, so
+    this runs without a GPU: process group, SUM / MAX aggregation, rank 0's line relayed by the parent."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["KG_BENCH_BACKEND"] = "gloo"
+    for extra, tp in ((["--gpus", "2"], 1), (["--tp", "2"], 2)):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launch-check"] + extra,
+                             capture_output=True, text=True, env=env, timeout=240)
+        assert out.returncode == 0, out.stderr[-2000:]
+        j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert j["n_gpus"] == 2 and j["tp"] == tp and j["ranks"] == [[0, 0], [1, 1]]
+        assert j["tokens"] == 201.0 and j["t_job"] == 2.0          # SUM over ranks, MAX over ranks
+    # a rank count that does not fill whole tensor-parallel groups is refused before anything starts
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launch-check", "--gpus", "3", "--tp", "2"],
+                         capture_output=True, text=True, env=env, timeout=60)
+    assert out.returncode != 0 and "multiple" in out.stderr
+
+
 def test_question_file_conversation_and_answer_file(tmp_path):
     """Host-side pieces of the question-file evaluation loop (no GPU): Vicuna turn format, question
     slicing, answer-file re-ordering."""

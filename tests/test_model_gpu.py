@@ -606,14 +606,14 @@ def _cut(shape, n_layers):
 
 @pytest.mark.parametrize("name,L,n_layers,dtype,tol,recipe", [
     ("vicuna-13b", 3, 5, torch.float16, LOGIT_TOL, (0.3, 10.0)),       # data/vicuna_13B_config.json:8-21, exit layer 3 (data/ge_data_all_vicuna.py:149-152)
-    ("llama-33b", 2, 4, torch.bfloat16, 3 * LOGIT_TOL, (0.3, 10.0)),   # d 6656 / F 17920 / 52 heads in bf16: the 2-wave o_proj split and bf16 MFMA at real size
+    ("llama-33b", 2, 4, torch.bfloat16, LOGIT_TOL, (0.3, 10.0)),       # d 6656 / F 17920 / 52 heads in bf16: the 2-wave o_proj split and bf16 MFMA at real size
     ("vicuna-7b", 2, 4, torch.float16, LOGIT_TOL, (0.3, 10.0)),
 ], ids=["13b-L3-5layers-f16", "33b-4layers-bf16", "7b-4layers-f16"])
 def test_real_layer_shapes_against_live_oracle(name, L, n_layers, dtype, tol, recipe):
     """The layer shapes of the benchmark configurations with the layer count cut so that the fp32 CPU oracle
     finishes in seconds: every kernel runs at its real K / N (two-chunk X prologue at d > 4096, the large-K
-    down_proj mode, the o_proj wave splits).  The bf16 case is held to 3e-2 instead of 1e-2: bf16 keeps 8
-    significand bits against fp16's 11, and the oracle it is compared with computes in fp32."""
+    down_proj mode, the o_proj wave splits).  The bf16 case is held to the same 1e-2 of the row's max-abs as the
+    fp16 ones; the measured error of every case is printed (pytest -s)."""
     shape = _cut(get_shape(name), n_layers)
     base, adapter = synth_state_dicts(shape, L, seed=61, dtype=dtype, recipe=Recipe.agreeable(*recipe), device="cuda")
     model = KangarooModel.from_state_dicts(shape, base, adapter, dtype, L)
@@ -631,7 +631,9 @@ def test_real_layer_shapes_against_live_oracle(name, L, n_layers, dtype, tol, re
         # logits of the prompt's last row: device vs oracle, within the stated tolerance of the row's max-abs
         dev_row = model.base_model(ids.cuda(), logits_rows="last").logits[0, -1].float().cpu()
         ref_row = om.base_model(ids).logits[0, -1]
-        assert float((dev_row - ref_row).abs().max()) <= tol * float(ref_row.abs().max())
+        err = float((dev_row - ref_row).abs().max()) / float(ref_row.abs().max())
+        print(f"[logits] {name} {n_layers} layers {str(dtype).split('.')[-1]} plen {plen}: last-row logits max-abs error {err:.2e} of the row's max-abs (bound {tol:.0e})")
+        assert err <= tol
         van = vanilla_forward(ids.cuda(), model, 2, new_tok)[0][0]
         assert van == out[0][:len(van)]
     del model, om

@@ -5,7 +5,7 @@ one-shot exchange (all_gather + sum in rank order) — against the unsplit layer
 rehearsal (LocalGroup), bit for bit.
 GPU: all ranks' shards of the remaining layers run one after the other on one device; the device's rank-order sum
 is compared bit for bit with a NumPy rank-order sum of the very partials the kernels produced, the hidden rows
-with the oracle (<= 1e-2 of max-abs in fp16, 3e-2 in bf16) and with the unsplit kernels, and the whole decode
+with the oracle (<= 1e-2 of max-abs, fp16 and bf16 alike) and with the unsplit kernels, and the whole decode
 loop with the oracle's ids."""
 import json
 import os
@@ -124,7 +124,7 @@ def _cut(shape, n):
 @gpu
 @pytest.mark.parametrize("name,n_layers,tp,dtype,tol", [
     ("tp-small", 4, 2, torch.float16, 1e-2), ("tp-small", 4, 4, torch.float16, 1e-2),
-    ("llama-33b", 4, 4, torch.bfloat16, 3e-2), ("llama-33b", 3, 8, torch.bfloat16, 3e-2),     # 52 heads over 8 ranks: 7 each, 4 zero heads
+    ("llama-33b", 4, 4, torch.bfloat16, 1e-2), ("llama-33b", 3, 8, torch.bfloat16, 1e-2),     # 52 heads over 8 ranks: 7 each, 4 zero heads
 ], ids=["small-tp2", "small-tp4", "33b-tp4-bf16", "33b-tp8-bf16"])
 def test_tp_verify_pass_on_one_device(name, n_layers, tp, dtype, tol):
     from kangaroo_amd.kangaroo_model import KangarooModel

@@ -45,6 +45,28 @@ def test_warmup_schedule():
     assert T.linear_warmup_lr(5e-5, 900000, 2000, 800000) == 0.0
 
 
+def test_every_rank_runs_the_same_number_of_steps():
+    """954 files, 8 ranks, batches of 4: 239 batches are not a multiple of 8.  Each step ends in a gradient all-reduce,
+    so a rank with one batch more would wait for its peers until the collective times out.  The order wraps round
+    instead (accelerate's even_batches), every file is still seen, and one rank keeps the reference's plain batching
+    with a short last batch (DataLoader(drop_last=False), train.py:217)."""
+    for n, bs, world in ((954, 4, 8), (10, 4, 2), (7, 2, 4), (3, 4, 2), (16, 4, 4)):
+        per_rank = [T.epoch_batches(n, bs, 5, r, world) for r in range(world)]
+        assert len({len(b) for b in per_rank}) == 1, (n, bs, world)
+        assert all(len(x) == bs for b in per_rank for x in b)
+        seen = [i for b in per_rank for x in b for i in x]
+        assert set(seen) == set(range(n))
+        assert len(seen) - n < world * bs + bs                 # wrapped indices: less than one global step plus the short batch's fill
+        # interleaved back, the ranks' batches are the epoch's order (wrapped at the end)
+        order = torch.randperm(n, generator=torch.Generator().manual_seed(5)).tolist()
+        flat = [i for step in zip(*per_rank) for x in step for i in x]
+        assert flat[:n] == order and all(flat[n + j] == order[j % n] for j in range(len(flat) - n))
+    one = T.epoch_batches(10, 4, 5, 0, 1)
+    assert [len(x) for x in one] == [4, 4, 2] and sorted(i for x in one for i in x) == list(range(10))
+    assert T.epoch_batches(0, 4, 0, 0, 2) == []
+    assert T.epoch_batches(10, 4, 5, 0, 2) != T.epoch_batches(10, 4, 6, 0, 2)      # the seed (epoch index) reshuffles
+
+
 def test_no_cpu_training_path():
     if torch.cuda.is_available():
         pytest.skip("a GPU is present")
