@@ -6,7 +6,8 @@
  * are HIP device pointers owned by the caller (PyTorch allocates them); the library
  * never frees caller memory.  Every function returns 0 on success and a negative code
  * on failure (-1 bad argument, -2 HIP error, -3 does not fit on chip, -4 an opt-in persistent pass
- * gave up at a grid barrier and was switched off for the session: call again);
+ * gave up at a grid barrier and was switched off for the session: call again, -5 a tensor-parallel peer did not
+ * deliver its partial sums in time);
  * kg_last_error() gives the text.  Nothing throws.  `stream` is a hipStream_t passed
  * as void* (torch.cuda.current_stream().cuda_stream).
  *
@@ -260,6 +261,48 @@ int kg_generate(kg_session* s, int mode, const int32_t* prompt_host, int context
                 int max_length, int steps, double threshold, int eos_token_id,
                 int32_t* out_tokens_host, int32_t* accept_log_host, int accept_log_capacity,
                 kg_gen_result* result, void* stream);
+
+/* ---- tensor-parallel remaining layers (the >= 33B-class configuration) --------------
+ * The reference only places whole layers on GPUs one after the other (device_map="auto",
+ * kangaroo/kangaroo_model.py:22).  Here the layers [exit_layer, N) of a session can be SHARDS: q/k/v and gate/up are
+ * split by output rows (whole heads, slices of the MLP width), o_proj and down_proj by input columns, so that every
+ * rank produces fp32 partial sums [rows, d] which are added up in rank order on every rank (identical bits
+ * everywhere); layers [0, exit_layer), adapter and head stay replicated.  After kg_session_set_tp every entry point
+ * of the session (kg_generate's prefill and captured rounds, kg_forward_layers) runs the remaining layers that way.
+ *
+ * The exchange is one kernel per row-split projection: each rank copies its partial into its slot of every peer's
+ * exchange buffer over the direct links, raises a flag there, waits for the peers' flags in its own buffer and sums
+ * the slots (+ residual): one hop, no library collective, captured in the round graph like any other kernel.  The
+ * buffer lives in uncached device memory that peers map through an inter-process handle (kg_tp_xbuf_*); ranks must
+ * run the same passes in the same order.  A wait that outlasts about ten seconds raises an abort flag, after which no
+ * wait blocks and kg_generate / kg_forward_layers return -5.
+ * n_local == tp_size rehearses every rank on ONE GPU, shard after shard (no peers, no flags): bit-identical to a
+ * job with one rank per GPU, because every partial is produced by the same kernel on the same data either way. */
+#define KG_TP_MAX 8
+typedef struct {
+    int tp_size;                              /* ranks that share the remaining layers (2..8) */
+    int n_local;                              /* shards this session runs: 1 (one rank per GPU) or tp_size (rehearsal) */
+    int local_rank[KG_TP_MAX];                /* rank of each local shard */
+    int heads_local, kv_heads_local;          /* heads per shard (a head count tp_size does not divide is padded with zero heads) */
+    int ffn_local;                            /* intermediate_size / tp_size, a multiple of 32 */
+    const kg_layer_weights* layers[KG_TP_MAX];/* per local shard: host array of num_layers - exit_layer entries (copied);
+                                                 wqkv packed [(heads_local + 2 kv_heads_local) hd, d], wo [d, heads_local hd],
+                                                 wgu [2 ffn_local, d], wdown [d, ffn_local], norms replicated */
+    void* k_cache[KG_TP_MAX];                 /* per local shard: [num_layers - exit_layer][kv_heads_local][t_max][hd] */
+    void* v_cache[KG_TP_MAX];                 /* same, transposed as the session's v_cache is */
+    void* xbuf;                               /* this GPU's exchange buffer (kg_tp_xbuf_create) */
+    void* peer_xbuf[KG_TP_MAX];               /* by rank: that rank's exchange buffer as mapped into this process
+                                                 (kg_tp_xbuf_open); ignored for local ranks */
+} kg_tp_config;
+size_t kg_tp_xbuf_bytes(int tp_size, int hidden_size);
+/* Zero-filled uncached device memory on the current GPU + its 64-byte inter-process handle (may be NULL). */
+int kg_tp_xbuf_create(size_t bytes, void** out, void* ipc_handle_64);
+int kg_tp_xbuf_open(const void* ipc_handle_64, void** out);     /* a peer's buffer, mapped into this process */
+int kg_tp_xbuf_close(void* mapped);
+int kg_tp_xbuf_destroy(void* p);
+/* weights->layers[l] for l >= exit_layer and buffers->k_cache / v_cache beyond exit_layer layers are not used by a
+ * session in this mode (they may be NULL / absent). */
+int kg_session_set_tp(kg_session* s, const kg_tp_config* cfg);
 
 /* Measurement aid (no counterpart in the reference): replays `iters` launches of one of
  * the session's linear kernels, cycling over the layers' weights so that no launch finds

@@ -42,6 +42,16 @@ class KgGenResult(C.Structure):
                 ("stopped_on_eos", C.c_int), ("prefill_ms", C.c_float), ("decode_ms", C.c_float)]
 
 
+KG_TP_MAX = 8
+
+
+class KgTpConfig(C.Structure):
+    _fields_ = [("tp_size", C.c_int), ("n_local", C.c_int), ("local_rank", C.c_int * KG_TP_MAX),
+                ("heads_local", C.c_int), ("kv_heads_local", C.c_int), ("ffn_local", C.c_int),
+                ("layers", C.POINTER(KgLayerWeights) * KG_TP_MAX), ("k_cache", C.c_void_p * KG_TP_MAX), ("v_cache", C.c_void_p * KG_TP_MAX),
+                ("xbuf", C.c_void_p), ("peer_xbuf", C.c_void_p * KG_TP_MAX)]
+
+
 # every symbol include/kangaroo_hip.h declares: (name, restype, argtypes)
 _VP, _I, _F, _D, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 SYMBOLS = {
@@ -73,6 +83,12 @@ SYMBOLS = {
     "kg_final_norm": (_I, [_VP, _VP, _I, _VP, _VP]),
     "kg_adapter_forward": (_I, [_VP, _VP, _I, _I, _VP, _VP]),
     "kg_head_logits": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
+    "kg_tp_xbuf_bytes": (_SZ, [_I, _I]),
+    "kg_tp_xbuf_create": (_I, [_SZ, C.POINTER(_VP), _VP]),
+    "kg_tp_xbuf_open": (_I, [_VP, C.POINTER(_VP)]),
+    "kg_tp_xbuf_close": (_I, [_VP]),
+    "kg_tp_xbuf_destroy": (_I, [_VP]),
+    "kg_session_set_tp": (_I, [_VP, C.POINTER(KgTpConfig)]),
     "kg_bench_op": (_I, [_VP, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_size_t)]),
     "kg_train_rmsnorm_fwd": (_I, [_I, _VP, _VP, _F, _I, _I, _VP, _VP, _VP]),
     "kg_train_rmsnorm_bwd_scratch": (_SZ, [_I, _I]),

@@ -76,6 +76,14 @@ struct kg_session {
     int bench_layers;                  // kg_bench_op cycles through this many layers' weights (1: cache-warm)
     unsigned long long* tlog;          // phase timeline of the last persistent launch (KG_PERSIST_TLOG=1), else null
     std::vector<int> prog_kinds[3];
+    // tensor-parallel remaining layers (kg_session_set_tp); size == 0: the session holds whole layers
+    struct {
+        int size, n_local, rank[KG_TP_MAX], hl, hkvl, fl;
+        std::vector<kg_layer_weights> layers[KG_TP_MAX];
+        void* kc[KG_TP_MAX]; void* vc[KG_TP_MAX];
+        float* xbuf; float* peer[KG_TP_MAX];
+        unsigned local_mask;
+    } tp;
     // graphs
     hipStream_t own_stream;
     hipGraphExec_t round_graph; int round_graph_steps;
@@ -178,6 +186,7 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     s->layers.assign(weights->layers, weights->layers + shape->num_layers);
     s->w.layers = s->layers.data();
     s->elt = 2;
+    s->tp.size = 0; s->tp.n_local = 0; s->tp.xbuf = nullptr; s->tp.local_mask = 0;
     s->q_dim = shape->num_heads * shape->head_dim;
     s->kv_dim = shape->num_kv_heads * shape->head_dim;
     Carver c{(char*)buffers->workspace, 0};
@@ -257,7 +266,7 @@ extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
     if (k == "attn_prefetch_delay") { s->attn_prefetch_delay = value - 1; done = true; }
     if (k == "attn_prefetch_min") { s->attn_prefetch_min = value; done = true; }
     if (k == "attn_blocks") { if (value > 32) return fail(-1, "attn_blocks <= 32"); s->attn_blocks = value; done = true; }
-    if (k == "persist") { s->persist = (value >= 2 && s->v_transposed && (g_ncu % 8) == 0) ? 1 : 0; done = true; }   // 1: off, 2: on
+    if (k == "persist") { s->persist = (value >= 2 && s->v_transposed && (g_ncu % 8) == 0 && s->tp.size == 0) ? 1 : 0; done = true; }   // 1: off, 2: on
     for (int op = 0; op < 5 && !done; ++op)
         if (k == std::string("persist.") + kg_op_names[op] + ".waves") { if (value > 8) return fail(-1, "waves <= 8"); s->persist_waves[op] = value; done = true; }
     for (int mode = 0; mode < 2 && !done; ++mode) {
@@ -416,8 +425,94 @@ static int run_layer(kg_session* s, const kg_layer_weights& lw, void* kc, void* 
     return 0;
 }
 
+static bool tp_remote(const kg_session* s) { return s->tp.size > 1 && s->tp.local_mask != ((1u << s->tp.size) - 1u); }
+
+static int tp_reduce(kg_session* s, const KgDyn* dyn, int max_rows, int e, const void* resid, void* out, hipStream_t st) {
+    KgTpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dyn = dyn; a.xbuf = s->tp.xbuf;
+    for (int r = 0; r < KG_TP_MAX; ++r) a.peer[r] = s->tp.peer[r];
+    a.tp = s->tp.size; a.d = s->sh.hidden_size; a.local_mask = s->tp.local_mask;
+    a.e = e; a.exch_per_pass = 2 * (s->sh.num_layers - s->sh.exit_layer);
+    a.resid = resid; a.resid_stride = a.d; a.out = out; a.out_stride = a.d;
+    return kg_launch_tp_reduce(a, max_rows, s->sh.dtype, st);
+}
+static float* tp_slot(kg_session* s, int e, int rank) {
+    return s->tp.xbuf + ((size_t)(e & 1) * s->tp.size + rank) * kg_tp_slot_floats(s->sh.hidden_size);
+}
+// waves of a row-split projection's MFMA launch on a shard: K is a fraction of the unsplit K, so the X rows fit LDS
+// and eight waves share a row group (the unsplit large-K mode streams X and does best with fewer)
+static int tp_waves(const kg_session* s, int max_rows, int op, int K) {
+    if (max_rows == 1) return s->waves[0][op];
+    return ((size_t)max_rows * K * 2 <= 64 * 1024) ? 8 : s->waves[1][op];
+}
+
+// Layer l >= exit_layer of a session whose remaining layers are shards (kg_session_set_tp): every local shard runs
+// qkv -> attention -> its columns of o_proj (fp32 partial sums into its slot of the exchange buffer), one exchange
+// kernel adds the ranks' slots and the residual; the same for gate/up -> its columns of down_proj.  5 kernels per
+// shard and 2 per layer.  h_in / h_out may alias.
+static int run_layer_tp(kg_session* s, int l, const KgDyn* dyn, int max_rows, const void* h_in, void* h_out, hipStream_t st) {
+    const kg_shape& sh = s->sh;
+    const int d = sh.hidden_size, dt = sh.dtype, hd = sh.head_dim, li = l - sh.exit_layer, e0 = 2 * li;
+    const int qd = s->tp.hl * hd, kvd = s->tp.hkvl * hd, fl = s->tp.fl;
+    const size_t cache_layer = (size_t)s->tp.hkvl * s->buf.t_max * hd * s->elt;
+    for (int j = 0; j < s->tp.n_local; ++j) {
+        const kg_layer_weights& lw = s->tp.layers[j][li];
+        void* kc = (char*)s->tp.kc[j] + (size_t)li * cache_layer;
+        void* vc = (char*)s->tp.vc[j] + (size_t)li * cache_layer;
+        {
+            KgLinArgs a = lin_base(dyn, lw.wqkv, qd + 2 * kvd, d, h_in, d);
+            a.norm_w = lw.norm1; a.eps = sh.rms_eps;
+            a.q_out = s->xq; a.k_cache = kc; a.v_cache = vc;
+            a.rope_cos = s->w.rope_cos; a.rope_sin = s->w.rope_sin;
+            a.head_dim = hd; a.q_dim = qd; a.kv_dim = kvd; a.t_max = s->buf.t_max; a.v_transposed = s->v_transposed;
+            KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_RMSNORM, EPI_ROPE_KV, grid_for(s, a.N, max_rows, OP_QKV), waves_for(s, max_rows, OP_QKV), st));
+        }
+        {
+            KgAttnArgs a;
+            memset(&a, 0, sizeof(a));
+            a.dyn = dyn; a.q = s->xq; a.k_cache = kc; a.v_cache = vc;
+            a.H = s->tp.hl; a.Hkv = s->tp.hkvl; a.hd = hd; a.t_max = s->buf.t_max; a.v_transposed = s->v_transposed;
+            a.nsplit = s->attn_nsplit; a.blocks_per_head = s->attn_blocks; a.teams = s->attn_teams; a.part_o = s->part_o; a.part_ml = s->part_ml; a.counters = s->attn_counters; a.out = s->attn_out; a.max_rows = max_rows;
+            KG_TRY(kg_launch_attn(a, dt, st));
+        }
+        {
+            KgLinArgs a = lin_base(dyn, lw.wo, d, qd, s->attn_out, qd);
+            a.out = tp_slot(s, e0, s->tp.rank[j]); a.out_stride = d;
+            KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_NONE, EPI_STORE_F32, grid_for(s, a.N, max_rows, OP_O), tp_waves(s, max_rows, OP_O, qd), st));
+        }
+    }
+    KG_TRY(tp_reduce(s, dyn, max_rows, e0, h_in, h_out, st));
+    for (int j = 0; j < s->tp.n_local; ++j) {
+        const kg_layer_weights& lw = s->tp.layers[j][li];
+        {
+            KgLinArgs a = lin_base(dyn, lw.wgu, 2 * fl, d, h_out, d);
+            a.norm_w = lw.norm2; a.eps = sh.rms_eps;
+            a.out = s->act; a.out_stride = fl;
+            KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_RMSNORM, EPI_SILU_MUL, grid_for(s, a.N, max_rows, OP_GATEUP), waves_for(s, max_rows, OP_GATEUP), st));
+        }
+        {
+            KgLinArgs a = lin_base(dyn, lw.wdown, d, fl, s->act, fl);
+            a.out = tp_slot(s, e0 + 1, s->tp.rank[j]); a.out_stride = d;
+            KG_TRY(kg_launch_linear(a, dt, max_rows, PRO_NONE, EPI_STORE_F32, grid_for(s, a.N, max_rows, OP_DOWN), tp_waves(s, max_rows, OP_DOWN, fl), st));
+        }
+    }
+    return tp_reduce(s, dyn, max_rows, e0 + 1, h_out, h_out, st);
+}
+// after the last sharded layer of a pass: the exchange flags of the next pass carry higher numbers
+static int tp_pass_end(kg_session* s, const KgDyn* dyn, hipStream_t st) {
+    if (!tp_remote(s)) return 0;
+    return kg_launch_tp_pass_end(dyn, s->tp.xbuf, s->tp.size, s->sh.hidden_size, st);
+}
+static bool is_tp_layer(const kg_session* s, int l) { return s->tp.size > 1 && l >= s->sh.exit_layer; }
+
 static void* layer_k(kg_session* s, int l) { return (char*)s->buf.k_cache + (size_t)l * s->sh.num_kv_heads * s->buf.t_max * s->sh.head_dim * s->elt; }
 static void* layer_v(kg_session* s, int l) { return (char*)s->buf.v_cache + (size_t)l * s->sh.num_kv_heads * s->buf.t_max * s->sh.head_dim * s->elt; }
+// base layer l on the rows of dyn, whole or sharded
+static int run_layer_at(kg_session* s, int l, const KgDyn* dyn, int max_rows, const void* h_in, void* h_out, hipStream_t st) {
+    if (is_tp_layer(s, l)) return run_layer_tp(s, l, dyn, max_rows, h_in, h_out, st);
+    return run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), dyn, max_rows, h_in, h_out, st);
+}
 
 // lm_head on rows of x; prologue RMSNorm with norm_w when given.  Leaves per-block
 // (max, sum, argmax) records in head_part; returns the block count through *nblocks.
@@ -450,6 +545,86 @@ static int persist_head_records(const kg_session* s) { const int G = (s->sh.voca
 static int build_program(kg_session* s, int which, const KgDyn* dyn, int max_rows, int l0, int l1, const void* x_in, void* hbuf, bool with_head);
 static int run_program(kg_session* s, int which, hipStream_t st);
 
+// host side of the exchange's time-out: a wait that gave up left the abort word set
+static int tp_check_abort(kg_session* s, hipStream_t st) {
+    if (!tp_remote(s)) return 0;
+    unsigned aborted = 0;
+    const size_t off = (kg_tp_data_floats(s->tp.size, s->sh.hidden_size) + 2 * (size_t)s->tp.size * KG_TP_FLAG_BLOCKS + 1) * 4;
+    KG_CHECK_HIP(hipMemcpyAsync(&aborted, (char*)s->tp.xbuf + off, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    KG_CHECK_HIP(hipStreamSynchronize(st));
+    if (aborted) return fail(-5, "a tensor-parallel peer did not deliver its partial sums in time; the session's exchange is switched off (results of this call are invalid)");
+    return 0;
+}
+
+extern "C" size_t kg_tp_xbuf_bytes(int tp_size, int hidden_size) {
+    if (tp_size < 2 || tp_size > KG_TP_MAX || hidden_size < 32) return 0;
+    return align_up(kg_tp_total_bytes(tp_size, hidden_size), 4096);
+}
+extern "C" int kg_tp_xbuf_create(size_t bytes, void** out, void* ipc_handle_64) {
+    g_err.clear();
+    if (!out || bytes == 0) return fail(-1, "bad argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle is passed around as 64 bytes");
+    void* p = nullptr;
+    // uncached: every access goes to memory, so what a peer GPU stores here is seen without cache maintenance
+    KG_CHECK_HIP(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached));
+    hipError_t e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess && ipc_handle_64) e = hipIpcGetMemHandle((hipIpcMemHandle_t*)ipc_handle_64, p);
+    if (e != hipSuccess) { (void)hipFree(p); kg_set_error("exchange buffer set-up", e); return -2; }
+    *out = p;
+    return 0;
+}
+extern "C" int kg_tp_xbuf_open(const void* ipc_handle_64, void** out) {
+    g_err.clear();
+    if (!ipc_handle_64 || !out) return fail(-1, "bad argument");
+    hipIpcMemHandle_t h;
+    memcpy(&h, ipc_handle_64, sizeof(h));
+    KG_CHECK_HIP(hipIpcOpenMemHandle(out, h, hipIpcMemLazyEnablePeerAccess));
+    return 0;
+}
+extern "C" int kg_tp_xbuf_close(void* mapped) { g_err.clear(); if (mapped) KG_CHECK_HIP(hipIpcCloseMemHandle(mapped)); return 0; }
+extern "C" int kg_tp_xbuf_destroy(void* p) { g_err.clear(); if (p) KG_CHECK_HIP(hipFree(p)); return 0; }
+
+extern "C" int kg_session_set_tp(kg_session* s, const kg_tp_config* c) {
+    g_err.clear();
+    if (!s || !c) return fail(-1, "null argument");
+    const kg_shape& sh = s->sh;
+    const int n_deep = sh.num_layers - sh.exit_layer;
+    if (c->tp_size < 2 || c->tp_size > KG_TP_MAX) return fail(-1, "tp_size must be in [2, 8]");
+    if (n_deep < 1) return fail(-1, "the session has no remaining layers to shard");
+    if (c->n_local != 1 && c->n_local != c->tp_size) return fail(-1, "n_local must be 1 (one rank per GPU) or tp_size (all ranks rehearsed on one GPU)");
+    if (c->heads_local < 1 || c->kv_heads_local < 1 || c->heads_local % c->kv_heads_local) return fail(-1, "bad local head counts");
+    if (c->heads_local * c->tp_size < sh.num_heads || c->kv_heads_local * c->tp_size < sh.num_kv_heads) return fail(-1, "the shards do not cover every head");
+    if (c->ffn_local % 32 || c->ffn_local * c->tp_size != sh.intermediate_size) return fail(-1, "ffn_local must be intermediate_size / tp_size and a multiple of 32");
+    if (!c->xbuf) return fail(-1, "xbuf required");
+    unsigned mask = 0;
+    for (int j = 0; j < c->n_local; ++j) {
+        const int r = c->local_rank[j];
+        if (r < 0 || r >= c->tp_size || ((mask >> r) & 1u)) return fail(-1, "bad local_rank");
+        mask |= 1u << r;
+        if (!c->layers[j] || !c->k_cache[j] || !c->v_cache[j]) return fail(-1, "shard weights and caches required");
+        for (int i = 0; i < n_deep; ++i) {
+            const kg_layer_weights& lw = c->layers[j][i];
+            if (!lw.wqkv || !lw.wo || !lw.wgu || !lw.wdown || !lw.norm1 || !lw.norm2) return fail(-1, "a shard layer misses a weight");
+        }
+    }
+    for (int r = 0; r < c->tp_size; ++r)
+        if (!((mask >> r) & 1u) && !c->peer_xbuf[r]) return fail(-1, "peer_xbuf required for every rank that is not local");
+    s->tp.size = c->tp_size; s->tp.n_local = c->n_local; s->tp.hl = c->heads_local; s->tp.hkvl = c->kv_heads_local; s->tp.fl = c->ffn_local;
+    s->tp.local_mask = mask; s->tp.xbuf = (float*)c->xbuf;
+    for (int r = 0; r < KG_TP_MAX; ++r) s->tp.peer[r] = (r < c->tp_size && !((mask >> r) & 1u)) ? (float*)c->peer_xbuf[r] : nullptr;
+    for (int j = 0; j < c->n_local; ++j) {
+        s->tp.rank[j] = c->local_rank[j];
+        s->tp.layers[j].assign(c->layers[j], c->layers[j] + n_deep);
+        s->tp.kc[j] = c->k_cache[j]; s->tp.vc[j] = c->v_cache[j];
+    }
+    s->persist = 0;
+    if (s->round_graph) { hipGraphExecDestroy(s->round_graph); s->round_graph = nullptr; s->round_graph_steps = -1; }
+    if (s->vanilla_graph) { hipGraphExecDestroy(s->vanilla_graph); s->vanilla_graph = nullptr; }
+    s->prog_n[0] = s->prog_n[1] = s->prog_n[2] = 0;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------
 // model-level entry points
 // ---------------------------------------------------------------------------------
@@ -479,7 +654,7 @@ extern "C" int kg_forward_layers(kg_session* s, int layer_begin, int layer_end, 
         KG_TRY(kg_launch_embed(s->dyn_call, s->tokens, s->w.embed, d, s->h, d, st));
         cur = s->h;
     }
-    if (s->persist && n_rows >= 2) {
+    if (s->persist && n_rows >= 2 && s->tp.size == 0) {
         // the whole pass as one persistent kernel (rows live in the session's h2 buffer meanwhile)
         KG_CHECK_HIP(hipStreamSynchronize(st));
         KG_TRY(build_program(s, 2, s->dyn_call, max_rows, layer_begin, layer_end, cur, s->h2, false));
@@ -496,8 +671,12 @@ extern "C" int kg_forward_layers(kg_session* s, int layer_begin, int layer_end, 
     }
     for (int l = layer_begin; l < layer_end; ++l) {
         void* dst = (l == layer_end - 1) ? h_out : (void*)s->h;
-        KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_call, max_rows, cur, dst, st));
+        KG_TRY(run_layer_at(s, l, s->dyn_call, max_rows, cur, dst, st));
         cur = dst;
+    }
+    if (is_tp_layer(s, layer_end - 1)) {
+        KG_TRY(tp_pass_end(s, s->dyn_call, st));
+        KG_TRY(tp_check_abort(s, st));
     }
     return 0;
 }
@@ -675,9 +854,10 @@ static int enqueue_round(kg_session* s, int steps, hipStream_t st) {
     } else {
         const void* cur = s->exited;
         for (int l = L; l < N; ++l) {
-            KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_verify, vrows, cur, s->h2, st));
+            KG_TRY(run_layer_at(s, l, s->dyn_verify, vrows, cur, s->h2, st));
             cur = s->h2;
         }
+        KG_TRY(tp_pass_end(s, s->dyn_verify, st));
         KG_TRY(run_head(s, s->dyn_verify, vrows, s->h2, 0, s->w.final_norm, (s->accept_top_k > 1 || s->accept_top_p > 0.f || s->accept_typical) ? s->vlogits : nullptr, &nb, st));
     }
     if (s->accept_typical) KG_TRY(kg_launch_typical(b, s->vlogits, sh.vocab_size, s->temperature, s->typical_epsilon, s->typical_delta, s->topk_rank, sh.dtype, st));
@@ -701,7 +881,8 @@ static int enqueue_vanilla(kg_session* s, hipStream_t st) {
         // not the comparator of the losslessness tests: the remaining layers in GEMV arithmetic differ from
         // a verify row in summation order; this is the fastest plain decoding these kernels offer
         for (int l = 0; l < sh.num_layers; ++l)
-            KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_shallow, 1, s->h, s->h, st));
+            KG_TRY(run_layer_at(s, l, s->dyn_shallow, 1, s->h, s->h, st));
+        KG_TRY(tp_pass_end(s, s->dyn_shallow, st));
         KG_TRY(run_head(s, s->dyn_shallow, 1, s->h, 0, s->w.final_norm, nullptr, &nb, st));
     } else if (s->prog_n[1] > 0) {
         for (int l = 0; l < sh.exit_layer; ++l)
@@ -710,7 +891,8 @@ static int enqueue_vanilla(kg_session* s, hipStream_t st) {
         nb = persist_head_records(s);
     } else {
         for (int l = 0; l < sh.num_layers; ++l)
-            KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_shallow, l < sh.exit_layer ? 1 : 2, s->h, s->h, st));
+            KG_TRY(run_layer_at(s, l, s->dyn_shallow, l < sh.exit_layer ? 1 : 2, s->h, s->h, st));
+        KG_TRY(tp_pass_end(s, s->dyn_shallow, st));
         KG_TRY(run_head(s, s->dyn_shallow, 2, s->h, 0, s->w.final_norm, nullptr, &nb, st));
     }
     KG_TRY(kg_launch_vanilla_end(b, s->head_part, nb, st));
@@ -783,6 +965,58 @@ static int run_layer_gemm(kg_session* s, const kg_layer_weights& lw, void* kc, v
     return 0;
 }
 
+// The same for a sharded layer (kg_session_set_tp): the row-split projections stop at the fp32 sum of their K ranges,
+// written into the shard's slot of the exchange buffer; kg_tp_reduce_kernel adds the ranks and the residual.
+static int run_layer_gemm_tp(kg_session* s, int l, const KgDyn* dyn, const void* h_in, void* h_out, hipStream_t st) {
+    const kg_shape& sh = s->sh;
+    const int d = sh.hidden_size, dt = sh.dtype, hd = sh.head_dim, li = l - sh.exit_layer, e0 = 2 * li;
+    const int qd = s->tp.hl * hd, kvd = s->tp.hkvl * hd, fl = s->tp.fl;
+    const size_t cache_layer = (size_t)s->tp.hkvl * s->buf.t_max * hd * s->elt;
+    KG_TRY(kg_launch_rmsnorm(dyn, h_in, d, s->tp.layers[0][li].norm1, sh.rms_eps, d, s->pf_xn, d, dt, st));
+    for (int j = 0; j < s->tp.n_local; ++j) {
+        const kg_layer_weights& lw = s->tp.layers[j][li];
+        void* kc = (char*)s->tp.kc[j] + (size_t)li * cache_layer;
+        void* vc = (char*)s->tp.vc[j] + (size_t)li * cache_layer;
+        {
+            KgLinArgs a = lin_base(dyn, lw.wqkv, qd + 2 * kvd, d, s->pf_xn, d);
+            a.q_out = s->pf_xq; a.k_cache = kc; a.v_cache = vc;
+            a.rope_cos = s->w.rope_cos; a.rope_sin = s->w.rope_sin;
+            a.head_dim = hd; a.q_dim = qd; a.kv_dim = kvd; a.t_max = s->buf.t_max; a.v_transposed = s->v_transposed;
+            KG_TRY(kg_launch_gemm(a, dt, PRO_NONE, EPI_ROPE_KV, st));
+        }
+        {
+            KgAttnArgs a;
+            memset(&a, 0, sizeof(a));
+            a.dyn = dyn; a.q = s->pf_xq; a.k_cache = kc; a.v_cache = vc;
+            a.H = s->tp.hl; a.Hkv = s->tp.hkvl; a.hd = hd; a.t_max = s->buf.t_max; a.v_transposed = s->v_transposed;
+            a.nsplit = s->attn_nsplit; a.blocks_per_head = s->attn_blocks; a.teams = s->attn_teams; a.part_o = s->part_o; a.part_ml = s->part_ml; a.counters = s->attn_counters;
+            a.out = s->pf_ao; a.max_rows = KG_GEMM_ROWS;
+            KG_TRY(kg_launch_attn(a, dt, st));
+        }
+        {
+            KgLinArgs a = lin_base(dyn, lw.wo, d, qd, s->pf_ao, qd);
+            a.out = tp_slot(s, e0, s->tp.rank[j]); a.out_stride = d; a.kpart = s->pf_part; a.part_only = 1;
+            KG_TRY(kg_launch_gemm(a, dt, PRO_NONE, EPI_RESID, st));
+        }
+    }
+    KG_TRY(tp_reduce(s, dyn, KG_GEMM_ROWS, e0, h_in, h_out, st));
+    KG_TRY(kg_launch_rmsnorm(dyn, h_out, d, s->tp.layers[0][li].norm2, sh.rms_eps, d, s->pf_xn, d, dt, st));
+    for (int j = 0; j < s->tp.n_local; ++j) {
+        const kg_layer_weights& lw = s->tp.layers[j][li];
+        {
+            KgLinArgs a = lin_base(dyn, lw.wgu, 2 * fl, d, s->pf_xn, d);
+            a.out = s->pf_act; a.out_stride = fl;
+            KG_TRY(kg_launch_gemm(a, dt, PRO_NONE, EPI_SILU_MUL, st));
+        }
+        {
+            KgLinArgs a = lin_base(dyn, lw.wdown, d, fl, s->pf_act, fl);
+            a.out = tp_slot(s, e0 + 1, s->tp.rank[j]); a.out_stride = d; a.kpart = s->pf_part; a.part_only = 1;
+            KG_TRY(kg_launch_gemm(a, dt, PRO_NONE, EPI_RESID, st));
+        }
+    }
+    return tp_reduce(s, dyn, KG_GEMM_ROWS, e0 + 1, h_out, h_out, st);
+}
+
 // Prefill: all layers over the prompt in passes of C rows (128-row GEMM passes, or prefill_rows
 // rows through the decode kernels); keeps the input of the exit layer for the adapter's cache
 // (inference_kangaroo.py:30-38).
@@ -800,10 +1034,13 @@ static int prefill(kg_session* s, int T0, bool with_adapter, hipStream_t st) {
         const void* cur = hb;
         for (int l = 0; l < N; ++l) {
             void* dst = (l == L - 1) ? (void*)(s->hs_early + (size_t)c0 * rowb) : (void*)hb;
-            if (gemm) KG_TRY(run_layer_gemm(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_call, cur, dst, st, l > 0, l + 1 < N ? s->layers[l + 1].norm1 : nullptr));
-            else KG_TRY(run_layer(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_call, C, cur, dst, st));
+            if (gemm && is_tp_layer(s, l)) KG_TRY(run_layer_gemm_tp(s, l, s->dyn_call, cur, dst, st));
+            else if (gemm) KG_TRY(run_layer_gemm(s, s->layers[l], layer_k(s, l), layer_v(s, l), s->dyn_call, cur, dst, st, l > 0,
+                                                 (l + 1 < N && !is_tp_layer(s, l + 1)) ? s->layers[l + 1].norm1 : nullptr));
+            else KG_TRY(run_layer_at(s, l, s->dyn_call, C, cur, dst, st));
             cur = dst;
         }
+        KG_TRY(tp_pass_end(s, s->dyn_call, st));
     }
     // first new token from the last row's logits (:33-34); dyn_call still describes the last pass
     int nb = 0;
@@ -940,6 +1177,7 @@ extern "C" int kg_generate(kg_session* s, int mode, const int32_t* prompt_host, 
             return fail(-4, "persistent pass timed out at a grid barrier; persistent passes are now off for this session, call again");
         }
     }
+    KG_TRY(tp_check_abort(s, st));
     // the replay queued after the finishing one ran with the loop condition false: a no-op
     const int* fin = slot[final_slot];
     const int sidx = fin[KS_START];
@@ -964,7 +1202,8 @@ extern "C" int kg_bench_op(kg_session* s, int op, int rows, int iters, float* us
     if (!s || !us_per_launch || op < 0 || op > 4 || rows < 1 || rows > KG_MAX_ROWS || iters < 1 || iters > 4096) return fail(-1, "bad argument");
     hipStream_t st = s->own_stream;
     const kg_shape& sh = s->sh;
-    const int d = sh.hidden_size, F = sh.intermediate_size, dt = sh.dtype, N = s->bench_layers;
+    const int d = sh.hidden_size, F = sh.intermediate_size, dt = sh.dtype;
+    const int N = (s->tp.size > 1 && s->bench_layers > sh.exit_layer) ? sh.exit_layer : s->bench_layers;     // whole layers only
     KG_TRY(kg_launch_set_dyn(s->dyn_call, 1, rows, 0, st));
     KG_CHECK_HIP(hipStreamSynchronize(st));
     hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;

@@ -227,7 +227,7 @@ __global__ void __launch_bounds__((GEMM_NW + GEMM_LW) * 64) kg_gemm_kernel(const
     }
 #endif
     // ---- epilogue inputs through LDS (the X buffers are free now), laid out as the decode epilogues expect ----
-    if (EPI == EPI_RESID && KS > 1) {
+    if (EPI == EPI_RESID && (KS > 1 || a.part_only)) {
         // partial sums of this K range; kg_gemm_reduce_kernel adds the ranges and the residual
         if (loader) return;
         float* part = a.kpart + (size_t)blockIdx.y * KG_GEMM_ROWS * a.N;
@@ -298,6 +298,23 @@ __global__ void kg_gemm_reduce_kernel(const KgLinArgs a) {
     const kg_f4 v = ((p[0] + p[1]) + p[2]) + p[3];
 #pragma unroll
     for (int i = 0; i < 4; ++i) out[n + i] = T::from_f(T::to_f(res[n + i]) + kg_round<DT>(v[i]));
+}
+
+// out32[m][n] = sum over K ranges of part[s][m][n], ranges added in order, nothing else: the fp32 partial sums of a
+// tensor-parallel shard's row-split projection (a.out is float [rows][out_stride]); the sum over the ranks, the
+// rounding and the residual follow in kg_tp_reduce_kernel.
+__global__ void kg_gemm_reduce_f32_kernel(const KgLinArgs a) {
+    const KgDyn* dyn = a.dyn;
+    if (dyn->active == 0) return;
+    const int m = blockIdx.y;
+    if (m >= dyn->n_rows) return;
+    const int n = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (n >= a.N) return;
+    const int ks = a.ksplit > 1 ? a.ksplit : 1;
+    kg_f4 p[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) p[s] = (s < ks) ? *(const kg_f4*)(a.kpart + ((size_t)s * KG_GEMM_ROWS + m) * a.N + n) : kg_f4{0.f, 0.f, 0.f, 0.f};
+    *(kg_f4*)((float*)a.out + (size_t)m * a.out_stride + n) = ((p[0] + p[1]) + p[2]) + p[3];
 }
 
 // The same sum, one block per row, followed by the RMSNorm of the finished row for the next projection
@@ -426,11 +443,16 @@ int kg_launch_gemm(const KgLinArgs& a_in, int dtype, int pro, int epi, hipStream
         if (epi == EPI_RESID && pro == PRO_NONE && a.kpart && G <= 2 * g_gemm_ncu && a.N % 16 == 0) ks = NB >= 16 ? 4 : (NB >= 8 ? 2 : 1);
         a.ksplit = ks;
     }
+    if (a.part_only && (epi != EPI_RESID || !a.kpart || a.N % 16 || (a.out_stride & 3))) return -1;
     if (epi == EPI_ROPE_KV && (a.head_dim > 128 || (a.head_dim & 7) || !a.rope_cos || !a.rope_sin)) return -1;     // the loader waves stage rows x head_dim <= 128 x 128 floats
     int rc;
     if (pro != PRO_NONE) return -1;          // rows are normalised by kg_launch_rmsnorm before the pass
     rc = (dtype == KG_F16) ? launch_nw<KG_F16>(a, epi, st) : launch_nw<KG_BF16>(a, epi, st);
     if (rc) return rc;
+    if (a.part_only) {
+        hipLaunchKernelGGL(kg_gemm_reduce_f32_kernel, dim3((a.N / 4 + 255) / 256, KG_GEMM_ROWS), dim3(256), 0, st, a);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     const bool norm_after = (a.out_norm_w != nullptr && a.out_norm != nullptr);
     if (norm_after && epi != EPI_RESID) return -1;
     if (a.ksplit > 1 && norm_after) {

@@ -32,6 +32,9 @@ struct KgLinArgs {
     // prefill GEMM, EPI_RESID: RMSNorm (gamma out_norm_w, a.eps) of the finished output rows for the next
     // projection, written to out_norm [rows][N] (NULL: none)
     const void* out_norm_w; void* out_norm;
+    // prefill GEMM, EPI_RESID with kpart: 1 = stop at the fp32 sum of the K ranges, written to out as float
+    // [rows][out_stride] with no residual (a tensor-parallel shard's partial sums)
+    int part_only;
 };
 
 size_t kg_linear_smem(int mfma, int max_rows, int K, int nwaves);
@@ -116,5 +119,27 @@ int kg_launch_typical(const KgLoopBufs& b, const void* logits, int vocab, float 
 int kg_launch_topk_rank(const KgLoopBufs& b, const void* logits, int vocab, int* rank, int dtype, hipStream_t st);
 int kg_launch_vanilla_begin(const KgLoopBufs& b, hipStream_t st);
 int kg_launch_vanilla_end(const KgLoopBufs& b, const float* head_part, int nblocks, hipStream_t st);
+
+// ---- tensor-parallel exchange (tp.hip) ----
+#define KG_TP_MAX 8
+#define KG_TP_FLAG_BLOCKS 1024          // flags per (parity, source rank): one per block of the largest reduce launch
+#define KG_TP_ROWS_CAP KG_GEMM_ROWS     // rows a slot of the exchange buffer holds
+struct KgTpArgs {
+    const KgDyn* dyn;
+    float* xbuf;                        // this GPU's exchange buffer: [2][tp][KG_TP_ROWS_CAP][d] floats, flags [2][tp][KG_TP_FLAG_BLOCKS], control words
+    float* peer[KG_TP_MAX];             // by rank: that rank's exchange buffer as mapped here (unused for local ranks)
+    int tp, d;
+    unsigned local_mask;                // bit r: rank r's partial is produced on this GPU
+    int e, exch_per_pass;               // exchange index inside a pass (its parity picks the buffer half); exchanges per pass
+    const void* resid; int resid_stride;
+    void* out; int out_stride;
+};
+__host__ __device__ static inline size_t kg_tp_slot_floats(int d) { return (size_t)KG_TP_ROWS_CAP * d; }
+__host__ __device__ static inline size_t kg_tp_data_floats(int tp, int d) { return 2 * (size_t)tp * kg_tp_slot_floats(d); }
+__host__ __device__ static inline size_t kg_tp_total_bytes(int tp, int d) { return (kg_tp_data_floats(tp, d) + 2 * (size_t)tp * KG_TP_FLAG_BLOCKS + 64) * 4; }
+// out[m][:] = round16(resid[m][:] + round16(sum over ranks, in rank order, of slot[r][m][:])) after the one-shot exchange
+int kg_launch_tp_reduce(const KgTpArgs& a, int max_rows, int dtype, hipStream_t st);
+// end of a pass over the sharded layers (one thread): the pass counter the exchange flags are numbered from moves on
+int kg_launch_tp_pass_end(const KgDyn* dyn, float* xbuf, int tp, int d, hipStream_t st);
 
 void kg_set_error(const char* what, hipError_t e);

@@ -52,7 +52,10 @@ class KangarooEngine:
 
     def __init__(self, shape: LlamaShape, base_sd: Dict[str, torch.Tensor], adapter_sd: Dict[str, torch.Tensor],
                  exit_layer: int = 2, dtype: torch.dtype = torch.float16, device="cuda", max_length: int = 2048,
-                 release_source: bool = False):
+                 release_source: bool = False, tp_plan=None):
+        """tp_plan (kangaroo_amd.tp.TPPlan): the layers [exit_layer, N) are held as tensor-parallel shards (this
+        rank's, or every rank's to rehearse them on one GPU) and every pass of the session exchanges their partial
+        sums through the library's one-shot exchange kernel; the draft stack, adapter and head stay whole."""
         if not torch.cuda.is_available():
             raise _lib.KangarooHipError("no GPU visible: the Kangaroo decode path has no CPU fallback")
         self.lib = _lib.lib()
@@ -77,8 +80,10 @@ class KangarooEngine:
             self._keep.append(t)
             return t
 
+        self.tp_plan = tp_plan
+        n_whole = exit_layer if tp_plan is not None else shape.num_hidden_layers        # sharded layers are packed below
         layers = (_lib.KgLayerWeights * shape.num_hidden_layers)()
-        for i in range(shape.num_hidden_layers):
+        for i in range(n_whole):
             p = f"model.layers.{i}."
             lw = layers[i]
             lw.wqkv = keep(pack_qkv(get(base_sd, p + "self_attn.q_proj.weight"), get(base_sd, p + "self_attn.k_proj.weight"),
@@ -116,10 +121,11 @@ class KangarooEngine:
         t_max = (max_length + 31) // 32 * 32
         # V is cached transposed ([.., hd, t_max]) when the MFMA attention kernel applies
         self.v_transposed = hd >= 32
-        self.k_cache = torch.zeros((shape.num_hidden_layers, Hkv, t_max, hd), dtype=dtype, device=dev)
+        self.t_max = t_max
+        self.k_cache = torch.zeros((n_whole, Hkv, t_max, hd), dtype=dtype, device=dev)
         self.ak_cache = torch.zeros((Hkv, t_max, hd), dtype=dtype, device=dev)
         if self.v_transposed:
-            self.v_cache = torch.zeros((shape.num_hidden_layers, Hkv, hd, t_max), dtype=dtype, device=dev)
+            self.v_cache = torch.zeros((n_whole, Hkv, hd, t_max), dtype=dtype, device=dev)
             self.av_cache = torch.zeros((Hkv, hd, t_max), dtype=dtype, device=dev)
         else:
             self.v_cache = torch.zeros_like(self.k_cache)
@@ -133,10 +139,75 @@ class KangarooEngine:
         _lib.check(self.lib.kg_session_create(C.byref(ks), C.byref(w), C.byref(b), C.byref(h)), "kg_session_create")
         self._handle = h
         assert self.lib.kg_session_get(h, b"v_transposed") == int(self.v_transposed)
+        self._xbuf = None
+        self._peer_maps: List[int] = []
+        if tp_plan is not None:
+            self._setup_tp(base_sd, tp_plan)
         self.tokens = self._region("tokens", t_max * 4).view(torch.int32)
         self.hs_early = self._region("hs_early", t_max * shape.hidden_size * 2).view(dtype).view(t_max, shape.hidden_size)
 
     # ------------------------------------------------------------------
+    def _setup_tp(self, base_sd, plan):
+        """Shard, pack and register the remaining layers; create this GPU's exchange buffer and map the peers'."""
+        from .tp import padded_heads, shard_layer
+        shape, dev, dtype, L = self.shape, self.device, self.dtype, self.exit_layer
+        hd, tp = shape.head_dim, plan.size
+        hl, hkvl, fl = padded_heads(shape.num_attention_heads, tp) // tp, padded_heads(shape.num_key_value_heads, tp) // tp, shape.intermediate_size // tp
+        n_deep = shape.num_hidden_layers - L
+        cfg = _lib.KgTpConfig()
+        cfg.tp_size, cfg.n_local, cfg.heads_local, cfg.kv_heads_local, cfg.ffn_local = tp, len(plan.local_ranks), hl, hkvl, fl
+        self.tp_k, self.tp_v, self._tp_layers = [], [], []
+        for j, r in enumerate(plan.local_ranks):
+            arr = (_lib.KgLayerWeights * n_deep)()
+            for i in range(n_deep):
+                s = {k: v.to(device=dev, dtype=dtype) for k, v in shard_layer(base_sd, f"model.layers.{L + i}.", shape, tp, r).items()}
+                lw = arr[i]
+                keep = self._keep.append
+                t = pack_qkv(s["wq"], s["wk"], s["wv"], hl, hkvl, hd); keep(t); lw.wqkv = t.data_ptr()
+                t = pack_weight(s["wo"].contiguous()); keep(t); lw.wo = t.data_ptr()
+                t = pack_gate_up(s["wg"].contiguous(), s["wu"].contiguous()); keep(t); lw.wgu = t.data_ptr()
+                t = pack_weight(s["wd"].contiguous()); keep(t); lw.wdown = t.data_ptr()
+                t = s["norm1"].contiguous(); keep(t); lw.norm1 = t.data_ptr()
+                t = s["norm2"].contiguous(); keep(t); lw.norm2 = t.data_ptr()
+            self._tp_layers.append(arr)
+            k = torch.zeros((n_deep, hkvl, self.t_max, hd), dtype=dtype, device=dev)
+            v = torch.zeros((n_deep, hkvl, hd, self.t_max) if self.v_transposed else (n_deep, hkvl, self.t_max, hd), dtype=dtype, device=dev)
+            self.tp_k.append(k); self.tp_v.append(v)
+            cfg.local_rank[j] = r
+            cfg.layers[j] = arr
+            cfg.k_cache[j], cfg.v_cache[j] = k.data_ptr(), v.data_ptr()
+        nbytes = self.lib.kg_tp_xbuf_bytes(tp, shape.hidden_size)
+        handle = C.create_string_buffer(64)
+        xb = C.c_void_p(0)
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.kg_tp_xbuf_create(nbytes, C.byref(xb), handle), "kg_tp_xbuf_create")
+        self._xbuf, self.xbuf_bytes = xb.value, nbytes
+        cfg.xbuf = xb.value
+        if len(plan.local_ranks) < tp:
+            handles = plan.exchange_handles(bytes(handle.raw))          # every rank's handle, by rank
+            for r in range(tp):
+                if r in plan.local_ranks:
+                    continue
+                m = C.c_void_p(0)
+                with torch.cuda.device(dev):
+                    _lib.check(self.lib.kg_tp_xbuf_open(C.create_string_buffer(handles[r], 64), C.byref(m)), "kg_tp_xbuf_open")
+                self._peer_maps.append(m.value)
+                cfg.peer_xbuf[r] = m.value
+        self._tp_cfg = cfg
+        _lib.check(self.lib.kg_session_set_tp(self._handle, C.byref(cfg)), "kg_session_set_tp")
+
+    def tp_partials(self, exchange: int) -> torch.Tensor:
+        """The fp32 partial sums [tp, rows_cap, d] the ranks left in this GPU's exchange buffer for exchange index
+        `exchange` of the last pass (2 * layer for o_proj, + 1 for down_proj): a copy, for tests."""
+        tp, d, cap = self.tp_plan.size, self.shape.hidden_size, 128
+        off = (exchange & 1) * tp * cap * d * 4
+
+        class _Raw:         # the library owns this memory: wrap the address, copy out
+            __cuda_array_interface__ = {"shape": (tp, cap, d), "typestr": "<f4", "data": (self._xbuf + off, False), "version": 2}
+
+        torch.cuda.synchronize(self.device)
+        return torch.as_tensor(_Raw(), device=self.device).clone()
+
     def _region(self, name: str, nbytes: int) -> torch.Tensor:
         p = self.lib.kg_session_ptr(self._handle, name.encode())
         if not p:
@@ -145,9 +216,13 @@ class KangarooEngine:
         return self.workspace[off:off + nbytes]
 
     def kv_views(self, layer: int, length: int):
-        """(k, v) of one base layer as [1, Hkv, length, hd] views of the in-place caches."""
-        k = self.k_cache[layer, :, :length, :].unsqueeze(0)
-        v = self.v_cache[layer, :, :, :length].transpose(-1, -2) if self.v_transposed else self.v_cache[layer, :, :length, :]
+        """(k, v) of one base layer as [1, Hkv, length, hd] views of the in-place caches (a sharded layer: the heads
+        of this process's first shard)."""
+        kc, vc, i = self.k_cache, self.v_cache, layer
+        if self.tp_plan is not None and layer >= self.exit_layer:
+            kc, vc, i = self.tp_k[0], self.tp_v[0], layer - self.exit_layer
+        k = kc[i, :, :length, :].unsqueeze(0)
+        v = vc[i, :, :, :length].transpose(-1, -2) if self.v_transposed else vc[i, :, :length, :]
         return k, v.unsqueeze(0)
 
     def adapter_kv_views(self, length: int):
@@ -159,6 +234,12 @@ class KangarooEngine:
         if self._handle:
             self.lib.kg_session_destroy(self._handle)
             self._handle = C.c_void_p(0)
+            for m in self._peer_maps:
+                self.lib.kg_tp_xbuf_close(C.c_void_p(m))
+            self._peer_maps = []
+            if self._xbuf:
+                self.lib.kg_tp_xbuf_destroy(C.c_void_p(self._xbuf))
+                self._xbuf = None
 
     def __del__(self):
         try:

@@ -20,6 +20,19 @@ tests exercise this file where only one GPU is at hand.
 
 The arithmetic of a layer equals the unsplit kernels' except for the order of the fp32 additions over K:
 h_mid = round16(h + round16(sum_r partial_r)), as the residual epilogue computes round16(h + round16(y)).
+
+Two ways to run it:
+
+  NativeTPKangarooModel   the library holds the shards (kg_session_set_tp): every pass of the session, the fused
+                          device-side loop (kg_generate: prefill in 128-row GEMM passes, one captured graph per round)
+                          included, runs 5 kernels per shard and layer plus one exchange kernel per row-split
+                          projection, which pushes the partial into the peers' exchange buffers over the direct
+                          links, waits for theirs and adds them up in rank order (csrc/tp.hip).  No host step and
+                          no library collective inside a round.
+  TPKangarooModel         the same partition driven pass by pass from Python over the kernel-level entry points, the
+                          exchange a torch.distributed all_gather (RCCL) captured with the kernels in one graph per
+                          row count: the comparison point for the exchange kernel, and the path for process groups
+                          whose ranks cannot map each other's memory.
 """
 from __future__ import annotations
 
@@ -98,6 +111,31 @@ def ordered_sum(parts: torch.Tensor) -> torch.Tensor:
 def add_residual(resid: torch.Tensor, total: torch.Tensor) -> torch.Tensor:
     """round16(resid + round16(total)): the residual epilogue's arithmetic (kangaroo/adapter.py:304 on 16-bit tensors)."""
     return (resid.float() + total.to(resid.dtype).float()).to(resid.dtype)
+
+
+class TPPlan:
+    """Which ranks' shards a session holds and how the ranks swap the handles of their exchange buffers.
+    TPPlan.local(tp): all ranks on this GPU (single-GPU rehearsal).  TPPlan.distributed(group): this process is one
+    rank of a torch.distributed group (any backend: only 64-byte handles travel through it, once, at set-up)."""
+
+    def __init__(self, size: int, local_ranks: Sequence[int], group=None):
+        self.size, self.local_ranks, self.group = size, list(local_ranks), group
+
+    @classmethod
+    def local(cls, tp: int) -> "TPPlan":
+        return cls(tp, range(tp))
+
+    @classmethod
+    def distributed(cls, group=None) -> "TPPlan":
+        import torch.distributed as dist
+        return cls(dist.get_world_size(group), [dist.get_rank(group)], group if group is not None else True)
+
+    def exchange_handles(self, mine: bytes) -> List[bytes]:
+        import torch.distributed as dist
+        group = None if self.group is True else self.group
+        out = [None] * self.size
+        dist.all_gather_object(out, mine, group=group)
+        return out
 
 
 class LocalGroup:
@@ -364,6 +402,28 @@ class TPKangarooModel:
         ranks = range(group.tp) if isinstance(group, LocalGroup) else [group.rank if rank is None else rank]
         self.shards = [TPShard(shape, base_sd, L, group.tp, r, dtype, device, max_length) for r in ranks]
         self.base_model = TPEarlyExitLlamaForCausalLM(self.engine, self.shards, group, L, shape.num_hidden_layers, graphs=graphs)
+        self.adapter_model = AdapterModel(self.engine)
+        self.head_model = HeadModel(self.engine)
+
+    def eval(self):
+        return self
+
+    def forward(self):
+        raise NotImplementedError
+
+
+class NativeTPKangarooModel:
+    """KangarooModel (kangaroo/kangaroo_model.py:12-47) whose remaining layers are tensor-parallel shards held by the
+    library (kg_session_set_tp): `base_model`, `adapter_model`, `head_model` and `engine` as KangarooModel has them, so
+    kangaroo_forward (fused, device-side rounds) and kangaroo_forward_stepwise both run on it unchanged."""
+
+    def __init__(self, shape: LlamaShape, base_sd, adapter_sd, dtype, EARLY_STOP_LAYER: int, plan: TPPlan,
+                 max_length: int = 2048, device="cuda"):
+        from .adapter import AdapterModel
+        from .kangaroo_model import HeadModel
+        L = EARLY_STOP_LAYER
+        self.engine = KangarooEngine(shape, base_sd, adapter_sd, exit_layer=L, dtype=dtype, device=device, max_length=max_length, tp_plan=plan)
+        self.base_model = EarlyExitLlamaForCausalLM(self.engine, L)
         self.adapter_model = AdapterModel(self.engine)
         self.head_model = HeadModel(self.engine)
 

@@ -728,7 +728,7 @@ def test_attention_geometry_does_not_change_results():
 def test_zz_explained_cases_equal_the_allow_list():
     """Runs last in this file: the near-tie escapes taken in this process are exactly the committed list (a new
     one already failed where it occurred; a listed one that no longer occurs must be struck from the list)."""
-    ran = {(e["case"], e["prompt"], e["kind"], e["position"]) for e in _SEEN}
+    ran = {(e["case"], e["prompt"], e["kind"], e["position"]) for e in _SEEN if not e["case"].startswith("tp:")}
     if os.environ.get("KG_EXPLAINED_UPDATE"):
         pytest.skip("allow-list is being regenerated")
     if not ran and not _ALLOW_KEYS:
@@ -737,4 +737,5 @@ def test_zz_explained_cases_equal_the_allow_list():
     import sys
     if any(a.startswith("tests/test_model_gpu.py::") or "-k" == a for a in sys.argv):
         pytest.skip("partial run")
-    assert ran == _ALLOW_KEYS, f"not on the list: {sorted(ran - _ALLOW_KEYS)}; listed but did not occur: {sorted(_ALLOW_KEYS - ran)}"
+    listed = {k for k in _ALLOW_KEYS if not k[0].startswith("tp:")}          # the tensor-parallel cases are checked where they run (tests/test_tp.py)
+    assert ran == listed, f"not on the list: {sorted(ran - listed)}; listed but did not occur: {sorted(listed - ran)}"

@@ -332,7 +332,7 @@ def test_command_line_trains_two_epochs_and_writes_an_adapter_the_decoder_loads(
     main(common + ["--start", "0"])
     main(common + ["--start", "1"])
     lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
-    assert [l["epoch"] for l in lines] == [0, 1] and all(l["batches"] == 4 for l in lines)       # 95 % of 10 files = 9, batches of 2
+    assert [l["epoch"] for l in lines] == [0, 1] and all(l["batches"] == 5 for l in lines)       # 95 % of 10 files = 9: four batches of 2 and a last one of 1 (drop_last=False)
     assert os.path.exists(os.path.join(cdir, "state_0.pt")) and os.path.exists(os.path.join(cdir, "state_1.pt"))
     trained = load_adapter_state_dict(cdir)
     assert set(trained) == set(adapter)
