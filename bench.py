@@ -173,22 +173,29 @@ def launch_check(a, rank, world):
 
 def main_tp(a, shape, L, ds, hs, tdt, dev, dist, rank, world):
     """--tp N: every group of N ranks holds ONE model whose remaining layers are split N ways (kangaroo_amd/tp.py);
-    the draft stack is replicated.  The loop is driven pass by pass from the host; a pass over the split layers (its
-    kernels and the exchanges of the partial sums between them) is one captured graph per row count, replayed at
-    changing positions (--tp-no-graphs launches it kernel by kernel).  Groups decode disjoint prompts; the job's
-    tokens are counted once per group."""
-    from kangaroo_amd.inference import kangaroo_forward_stepwise
-    from kangaroo_amd.tp import DistGroup, LocalGroup, TPKangarooModel
+    the draft stack is replicated.  Groups decode disjoint prompts; the job's tokens are counted once per group.
+    --tp-exchange p2p (default): the library holds the shards and the whole loop runs on the device as in the
+    single-GPU case, the partial sums exchanged by the one-shot peer-to-peer kernel inside the captured round.
+    --tp-exchange rccl: the loop is driven pass by pass from the host; a pass over the split layers (its kernels and
+    torch.distributed all_gathers between them) is one captured graph per row count, replayed at changing positions
+    (--tp-no-graphs launches it kernel by kernel)."""
+    from kangaroo_amd.inference import kangaroo_forward, kangaroo_forward_stepwise, vanilla_forward
+    from kangaroo_amd.tp import DistGroup, LocalGroup, NativeTPKangarooModel, TPKangarooModel, TPPlan
+    native = a.tp_exchange == "p2p"
+    pg = None
     if a.tp_local:
-        group, n_groups, gidx = LocalGroup(a.tp), world, rank
+        n_groups, gidx = world, rank
     else:
         if dist is None or world % a.tp:
             sys.exit(f"bench.py --tp {a.tp}: launch a multiple of {a.tp} ranks (WORLD_SIZE is {world}), or rehearse on one GPU with --tp-local")
         n_groups, gidx = world // a.tp, rank // a.tp
         pgs = [dist.new_group(list(range(g * a.tp, (g + 1) * a.tp))) for g in range(n_groups)]
-        group = DistGroup(pgs[gidx])
+        pg = pgs[gidx]
     base_sd, adapter_sd = synth_state_dicts(shape, L, seed=0, dtype=tdt, recipe=Recipe.agreeable(ds, hs), device=dev)
-    model = TPKangarooModel(shape, base_sd, adapter_sd, tdt, L, group, device=dev, graphs=not a.tp_no_graphs)
+    if native:
+        model = NativeTPKangarooModel(shape, base_sd, adapter_sd, tdt, L, TPPlan.local(a.tp) if a.tp_local else TPPlan.distributed(pg), device=dev)
+    else:
+        model = TPKangarooModel(shape, base_sd, adapter_sd, tdt, L, LocalGroup(a.tp) if a.tp_local else DistGroup(pg), device=dev, graphs=not a.tp_no_graphs)
     del base_sd, adapter_sd
     torch.cuda.empty_cache()
     K, W = a.steps, a.warmup
@@ -204,6 +211,11 @@ def main_tp(a, shape, L, ds, hs, tdt, dev, dist, rank, world):
         torch.cuda.synchronize()
 
     def run(p, steps):
+        if native:
+            # plain decoding = kg_generate's vanilla mode over the same sharded kernels (its remaining layers in a verify row's arithmetic)
+            if steps == 0:
+                return vanilla_forward(p.input_ids.to(dev), model, -1, new)
+            return kangaroo_forward(p.input_ids.to(dev), model, -1, new, EARLY_STOP_LAYER=L, SPECULATIVE_DECODING_STEPS=steps, threshold=a.threshold)
         model.head_model.single_rows_in_verify_arithmetic = (steps == 0)      # the comparator's lone rows in a verify row's arithmetic
         return kangaroo_forward_stepwise(p.input_ids.to(dev), model, -1, new, EARLY_STOP_LAYER=L, SPECULATIVE_DECODING_STEPS=steps, threshold=a.threshold)
 
@@ -218,12 +230,16 @@ def main_tp(a, shape, L, ds, hs, tdt, dev, dist, rank, world):
     # plain greedy decoding over the same kernels: the same loop with no draft steps (one shallow pass + one verify row per token)
     torch.cuda.synchronize()
     tv0 = time.time()
+    if native:
+        run(timed[0], 0)                                   # graph capture of the plain-decoding step outside its timed region
+        torch.cuda.synchronize()
+        tv0 = time.time()
     van = [run(p, 0) for p in timed]
     torch.cuda.synchronize()
     tv = time.time() - tv0
     agree = sum(int(v[0][0][:min(len(v[0][0]), len(o[0][0]))] == o[0][0][:min(len(v[0][0]), len(o[0][0]))]) for v, o in zip(van, outs))
     leader = a.tp_local or (rank % a.tp == 0)
-    tot = torch.tensor([float(new_tokens) if leader else 0.0, elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(new_tokens) if leader else 0.0, elapsed], dtype=torch.float64, device=dev if dist is None or dist.get_backend() == "nccl" else "cpu")
     if dist is not None:
         tmax = tot.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -240,7 +256,8 @@ def main_tp(a, shape, L, ds, hs, tdt, dev, dist, rank, world):
            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
            "config": {"workload": f"{a.model} shape {'fp16' if a.dtype == 'f16' else 'bf16'} Kangaroo exitlayer={L} steps={a.spec_steps} thr={a.threshold} greedy, "
                                   f"synthetic prompts <= 256 tokens, max_new_tokens={new}, remaining layers tensor-parallel x{a.tp} "
-                                  f"({'all ranks rehearsed on one GPU' if a.tp_local else 'RCCL all_gather + rank-order sum'}), pass-by-pass loop, {'one captured graph per pass' if not a.tp_no_graphs else 'kernel-by-kernel launches'}",
+                                  f"({'all ranks rehearsed on one GPU' if a.tp_local else ('one-shot peer-to-peer exchange kernel' if native else 'RCCL all_gather') + ' + rank-order sum'}), "
+                                  + ("device-side loop, one captured graph per round" if native else f"pass-by-pass loop, {'one captured graph per pass' if not a.tp_no_graphs else 'kernel-by-kernel launches'}"),
                       "prompts_per_group": K, "parallelism": f"tp{a.tp} x {n_groups} group(s)"},
            "mean_accept": sum(acc) / max(1, len(acc)),
            "vanilla_tokens_per_s_rank0": sum(v[1] for v in van) / tv, "speedup_vs_vanilla": (new_tokens / elapsed) / (sum(v[1] for v in van) / tv),
@@ -270,6 +287,8 @@ def main():
     ap.add_argument("--tp", type=int, default=1, help="tensor-parallel degree of the remaining-layer verify pass (the >= 33B-class configuration): "
                     "ranks form groups of this many GPUs, one replica per group")
     ap.add_argument("--tp-local", action="store_true", help="rehearse all --tp ranks of a group on ONE GPU, shard after shard (no process group)")
+    ap.add_argument("--tp-exchange", default="p2p", choices=["p2p", "rccl"], help="p2p: shards held by the library, exchange kernel inside the device-side round "
+                    "(ranks map each other's exchange buffers); rccl: host-driven passes with torch.distributed all_gather")
     ap.add_argument("--tp-no-graphs", action="store_true", help="launch the tensor-parallel pass kernel by kernel instead of replaying one captured graph per row count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-prompts", type=int, default=4, help="prompts of the bounded CPU-baseline sample (32 tokens in, 32 out each)")
