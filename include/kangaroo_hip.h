@@ -314,6 +314,27 @@ int kg_session_set_tp(kg_session* s, const kg_tp_config* cfg);
  * [0, rows) and the activation workspace: call it between generations only. */
 int kg_bench_op(kg_session* s, int op, int rows, int iters, float* us_per_launch, size_t* weight_bytes_per_launch);
 
+/* ---- dense matrix products of the compute-bound passes -------------------------------
+ * C[M][N] = alpha * A[M][K] . B[N][K]^T with fp32 accumulation on the matrix cores: torch.nn.functional.linear as the
+ * reference's layers and training loop call it on many rows at once (kangaroo/adapter.py:170-172,222 on a padded batch,
+ * the frozen head of train.py:265-273, and every product of their backward pass after a transpose of the operand whose
+ * contraction index is not contiguous).  A, B: 16-bit (dtype), row strides lda / ldb in elements, multiples of 8, K a
+ * multiple of 8; C: 16-bit, or fp32 when out_f32.  batch > 1: independent products at element strides sA / sB / sC
+ * (attention heads).  b_packed: B is a decode-path weight in the packed tile layout (K % 32 == 0, batch 1).
+ * causal 1: tiles of C entirely above the diagonal are neither computed nor written (scores of a causal attention);
+ * causal 2: A is lower triangular, so K is walked only up to each tile's last row (probabilities times values);
+ * causal 3: A is upper triangular, K is walked from each tile's first row on (transposed probabilities).
+ * kg_matmul_nt_heads: the batch index z = zo * batch_inner + zi addresses A at zo * sA + zi * sA2, C likewise and B at
+ * zo * sB + (zi / b_inner_div) * sB2: the heads of [batch, seq, heads, head_dim] tensors read in place, b_inner_div
+ * query heads sharing a key / value head (kangaroo/adapter.py:69-78). */
+int kg_matmul_nt(int dtype, const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                 int batch, long long sA, long long sB, long long sC, int b_packed, int out_f32, int causal, float alpha, void* stream);
+int kg_matmul_nt_heads(int dtype, const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                       int batch, long long sA, long long sB, long long sC, int batch_inner, long long sA2, long long sB2, long long sC2, int b_inner_div,
+                       int b_packed, int out_f32, int causal, float alpha, void* stream);
+/* out[b][c][r] = in[b][r][c] for 16-bit elements (row strides ld_in / ld_out, batch strides s_in / s_out, in elements). */
+int kg_transpose16(const void* in, void* out, int rows, int cols, long long ld_in, long long ld_out, int batch, long long s_in, long long s_out, void* stream);
+
 /* ---- adapter training step (train.py:258-296): the fused, memory-bound pieces ------
  * The step's matrix products are plain GEMMs over batch x sequence rows and stay with the BLAS library
  * (kangaroo_amd/train.py); these kernels do everything between them.  Activations are 16-bit (dtype),
@@ -338,9 +359,14 @@ int kg_train_softmax_bwd(int dtype, const void* probs, void* dprobs, int B, int 
 /* train.py:265-279 for rows of out-logits and target-logits [rows][vocab]: row_loss = -sum_v softmax(t)_v log_softmax(o)_v,
  * row_acc = sum_v min(softmax(t)_v, softmax(o)_v), and the gradient grad_scale * (softmax(o) - softmax(t)) written over
  * logits_out; rows with loss_mask 0 get zeros.  row_rank (may be NULL): how many out-logits lie above the out-logit of the
- * target's argmax token, i.e. the target is among the top k predictions iff rank < k (train.py:298-305); -1 outside the mask. */
-int kg_train_softce(int dtype, void* logits_out, const void* logits_tgt, const int* loss_mask, int rows, int vocab, float grad_scale,
+ * target's argmax token, i.e. the target is among the top k predictions iff rank < k (train.py:298-305); -1 outside the mask.
+ * row_stride >= vocab: elements between rows (the products that make the logits want rows of whole 16-byte pieces; columns
+ * beyond vocab are left alone). */
+int kg_train_softce(int dtype, void* logits_out, const void* logits_tgt, const int* loss_mask, int rows, int vocab, long long row_stride, float grad_scale,
                     float* row_loss, float* row_acc, int* row_rank, void* stream);
+/* y = y + x on n 16-bit elements (n a multiple of 8, 16-byte aligned), rounded once: the residual add of
+ * kangaroo/adapter.py:304 after the o_proj product. */
+int kg_train_add(int dtype, void* y, const void* x, long long n, void* stream);
 /* accelerator.clip_grad_value_(clip) + torch.optim.AdamW step `step` (1-based) on n fp32 parameters (train.py:227,285-286);
  * grad_dtype 0 fp16, 1 bf16, 2 fp32, multiplied by inv_scale first; p16 (may be NULL) receives the 16-bit copy
  * (copy_dtype) that the GEMMs read. */

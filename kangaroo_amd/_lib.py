@@ -89,6 +89,10 @@ SYMBOLS = {
     "kg_tp_xbuf_close": (_I, [_VP]),
     "kg_tp_xbuf_destroy": (_I, [_VP]),
     "kg_session_set_tp": (_I, [_VP, C.POINTER(KgTpConfig)]),
+    "kg_matmul_nt": (_I, [_I, _VP, _VP, _VP, _I, _I, _I, C.c_longlong, C.c_longlong, C.c_longlong, _I, C.c_longlong, C.c_longlong, C.c_longlong, _I, _I, _I, _F, _VP]),
+    "kg_matmul_nt_heads": (_I, [_I, _VP, _VP, _VP, _I, _I, _I, C.c_longlong, C.c_longlong, C.c_longlong, _I, C.c_longlong, C.c_longlong, C.c_longlong,
+                                _I, C.c_longlong, C.c_longlong, C.c_longlong, _I, _I, _I, _I, _F, _VP]),
+    "kg_transpose16": (_I, [_VP, _VP, _I, _I, C.c_longlong, C.c_longlong, _I, C.c_longlong, C.c_longlong, _VP]),
     "kg_bench_op": (_I, [_VP, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_size_t)]),
     "kg_train_rmsnorm_fwd": (_I, [_I, _VP, _VP, _F, _I, _I, _VP, _VP, _VP]),
     "kg_train_rmsnorm_bwd_scratch": (_SZ, [_I, _I]),
@@ -96,7 +100,8 @@ SYMBOLS = {
     "kg_train_rope": (_I, [_I, _VP, C.c_longlong, _I, _I, _I, _VP, _VP, _I, _VP]),
     "kg_train_softmax_fwd": (_I, [_I, _VP, _VP, _I, _I, _I, _F, _VP]),
     "kg_train_softmax_bwd": (_I, [_I, _VP, _VP, _I, _I, _I, _F, _VP]),
-    "kg_train_softce": (_I, [_I, _VP, _VP, _VP, _I, _I, _F, _VP, _VP, _VP, _VP]),
+    "kg_train_softce": (_I, [_I, _VP, _VP, _VP, _I, _I, C.c_longlong, _F, _VP, _VP, _VP, _VP]),
+    "kg_train_add": (_I, [_I, _VP, _VP, C.c_longlong, _VP]),
     "kg_train_adamw": (_I, [_VP, _VP, _VP, _VP, _I, _F, _F, _F, _F, _F, _F, _F, _I, C.c_longlong, _VP, _I, _VP]),
     "kg_generate": (_I, [_VP, _I, C.POINTER(C.c_int32), _I, _I, _I, _I, _D, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I,
                          C.POINTER(KgGenResult), _VP]),

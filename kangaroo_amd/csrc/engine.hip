@@ -25,6 +25,7 @@ static void kg_init_once() {
     kg_linear_init();
     kg_gemm_init();
     kg_attn_init();
+    kg_mm_init();
     int dev = 0;
     hipDeviceProp_t p;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_ncu = p.multiProcessorCount;
@@ -1387,6 +1388,36 @@ extern "C" int kg_head(int dtype, const void* w_packed, int vocab, int d, const 
     int rc = kg_launch_linear(a, dtype, n_rows, prologue, EPI_HEAD, nb, nwaves > 0 ? nwaves : 8, st);
     if (rc) return fail(rc, "kg_launch_linear failed");
     KG_TRY(kg_launch_head_finalize(dyn, a.head_part, a.head_part_stride, nb, n_rows, argmax_out, pmax_out, st));
+    return 0;
+}
+
+extern "C" int kg_matmul_nt(int dtype, const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                            int batch, long long sA, long long sB, long long sC, int b_packed, int out_f32, int causal, float alpha, void* stream) {
+    return kg_matmul_nt_heads(dtype, A, B, C, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, 1, 0, 0, 0, 1, b_packed, out_f32, causal, alpha, stream);
+}
+
+extern "C" int kg_matmul_nt_heads(int dtype, const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                                  int batch, long long sA, long long sB, long long sC, int batch_inner, long long sA2, long long sB2, long long sC2, int b_inner_div,
+                                  int b_packed, int out_f32, int causal, float alpha, void* stream) {
+    g_err.clear();
+    kg_init_once();
+    if (dtype != KG_F16 && dtype != KG_BF16) return fail(-1, "dtype");
+    KgMmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.batch = batch; a.sA = sA; a.sB = sB; a.sC = sC; a.b_packed = b_packed; a.out_f32 = out_f32; a.causal = causal; a.alpha = alpha;
+    a.batch_inner = batch_inner; a.sA2 = sA2; a.sB2 = sB2; a.sC2 = sC2; a.b_inner_div = b_inner_div;
+    { const char* t = getenv("KG_MM_TILE"); a.tile = t ? atoi(t) : 0; }      // measurements: 1 forces 128 x 128 tiles, 2 forces 256 x 256
+    const int rc = kg_launch_mm(a, dtype, (hipStream_t)stream);
+    if (rc == -1) return fail(-1, "kg_matmul_nt: bad shape (K and the row / batch strides of A and B must be multiples of 8; a packed B needs K % 32 == 0 and batch 1)");
+    if (rc) return fail(rc, "kg_matmul_nt launch failed");
+    return 0;
+}
+
+extern "C" int kg_transpose16(const void* in, void* out, int rows, int cols, long long ld_in, long long ld_out, int batch, long long s_in, long long s_out, void* stream) {
+    g_err.clear();
+    const int rc = kg_launch_transpose16(in, out, rows, cols, ld_in, ld_out, batch, s_in, s_out, (hipStream_t)stream);
+    if (rc) return fail(rc, "kg_transpose16: bad argument or launch failure");
     return 0;
 }
 

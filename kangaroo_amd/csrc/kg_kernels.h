@@ -120,6 +120,26 @@ int kg_launch_topk_rank(const KgLoopBufs& b, const void* logits, int vocab, int*
 int kg_launch_vanilla_begin(const KgLoopBufs& b, hipStream_t st);
 int kg_launch_vanilla_end(const KgLoopBufs& b, const float* head_part, int nblocks, hipStream_t st);
 
+// ---- dense matrix product (mm.hip): C[M][N] = alpha * A[M][K] . B[N][K]^T, fp32 accumulation ----
+struct KgMmArgs {
+    const void* A; const void* B; void* C;
+    int M, N, K;
+    long long lda, ldb, ldc;            // row strides in elements (ldb unused for a packed B)
+    long long sA, sB, sC; int batch;    // grid.z independent products z = zo * batch_inner + zi: element offsets zo * sX + zi * sX2
+    int batch_inner; long long sA2, sB2, sC2;   // (B: (zi / b_inner_div) * sB2, query heads that share a key / value head); batch_inner 1: z = zo
+    int b_inner_div;
+    int b_packed;                       // B in the packed 16 x 32 tile layout of the decode weights
+    int out_f32;                        // C is float instead of the 16-bit input type
+    int causal;                         // 1: tiles of C entirely above the diagonal are skipped (not written); 2: A is lower
+                                        //    triangular (row m has no entry beyond column m): K is walked up to the tile's last row;
+                                        // 3: A is upper triangular: K is walked from the tile's first row on
+    float alpha;
+    int tile;                           // 0: chosen by size; 1: 128 x 128 tiles; 2: 256 x 256 tiles (measurements)
+};
+int kg_launch_mm(const KgMmArgs& a, int dtype, hipStream_t st);
+void kg_mm_init();
+int kg_launch_transpose16(const void* in, void* out, int R, int Cn, long long ld_in, long long ld_out, int batch, long long s_in, long long s_out, hipStream_t st);
+
 // ---- tensor-parallel exchange (tp.hip) ----
 #define KG_TP_MAX 8
 #define KG_TP_FLAG_BLOCKS 1024          // flags per (parity, source rank): one per block of the largest reduce launch

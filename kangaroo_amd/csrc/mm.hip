@@ -1,0 +1,236 @@
+// Dense matrix product for the compute-bound parts of the path (gfx950): C[M][N] = A[M][K] . B[N][K]^T, both operands
+// with the contraction index contiguous ("x W^T", the form of torch.nn.functional.linear; kangaroo/adapter.py:170-172,222,
+// train.py:265-273).  16-bit inputs (fp16 / bf16), fp32 accumulation on v_mfma_f32_16x16x32, 16-bit or fp32 output.
+//
+// A block owns a BM x BN tile of C and walks K in steps of 64.  Per step its threads fetch BM x 64 of A and BN x 64 of
+// B with 16-byte buffer loads in whole 128-byte lines (eight consecutive lanes cover one row segment), park them in
+// registers while the MFMAs of the current step run, and write them to the other LDS buffer afterwards: one block
+// barrier per step.  LDS rows are 128 bytes; the 16-byte chunk index is XORed with (row >> 1) & 7 so that the 16 rows
+// x 16 bytes of a fragment read (ds_read_b128) fall on distinct banks.  Wave (wr, wc) computes a (BM / WM) x (BN / WN)
+// part of the tile, the B-matrix rows as the MFMA's A operand so that a lane ends up with four CONSECUTIVE output
+// columns of one row (an 8-byte store).
+// Two shapes: 256 x 256 with 8 waves of 128 x 64 (one block per CU: 128 KB of LDS, all 512 KB of registers) for
+// products with at least one tile per CU, and 128 x 128 with 4 waves of 64 x 64 (two blocks per CU) for the rest.
+// What decides between them is the path from L2 to the CUs, which carries about 10 TB/s: a 128 x 128 tile moves 32 KB
+// per 2.1 MFLOP step (64 flop per byte: ~670 TFLOP/s at that rate, which is what it measures), a 256 x 256 tile twice
+// the flops per byte.
+//
+// B can also be given in the decode path's packed layout (1 KiB tiles of 16 rows x 32 k, include/kangaroo_hip.h): the
+// staging loads then walk a tile's 64 pieces in storage order, one full tile per wave-level load.
+// Rows / columns beyond M / N and k beyond K are read as zeros through range-checked buffer loads (the offset of a
+// piece that does not exist is forced out of range), so any M, N and any K that is a multiple of 8 work.
+// grid.z walks `batch` independent products with element strides sA / sB / sC (attention heads).
+// Tiles are dealt to blocks so that the blocks resident on one XCD (block index mod 8) work on neighbouring tiles of a
+// band of 8 tile rows: they share the L2 copies of that band's A rows and of the B columns they walk.
+#include "kg_common.h"
+#include "kg_kernels.h"
+
+#define MM_BK 64
+
+__device__ __forceinline__ unsigned mm_lds_off(int row, int chunk) { return (unsigned)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)); }
+
+template <int DT, int BM, int BN, int WM, int WN, bool PACKED_B, bool OUT_F32>
+__global__ void __launch_bounds__(WM * WN * 64) kg_mm_kernel(const KgMmArgs a) {
+    typedef KgT<DT> T;
+    constexpr int MM_BM = BM, MM_BN = BN, NTHR = WM * WN * 64;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;            // MFMA tiles of a wave
+    constexpr int PA = BM * 8 / NTHR, PB = BN * 8 / NTHR;          // 16-byte pieces per thread and step
+    constexpr int A_BYTES = BM * MM_BK * 2, STAGE = (BM + BN) * MM_BK * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    // ---- tile of this block ----
+    const int tm = (a.M + MM_BM - 1) / MM_BM, tn = (a.N + MM_BN - 1) / MM_BN, nt = tm * tn;
+    int id = blockIdx.x;
+    {   // blocks that share an XCD (index mod 8) take consecutive tiles (bijective for any tile count)
+        const int q = nt >> 3, r = nt & 7, x = id & 7;
+        id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+    }
+    const int band = id / (8 * tn), in_band = id - band * 8 * tn;
+    const int band_rows = min(8, tm - band * 8);
+    const int tile_m = band * 8 + in_band % band_rows, tile_n = in_band / band_rows;
+    const int m0 = tile_m * MM_BM, n0 = tile_n * MM_BN;
+    if (a.causal == 1 && n0 > m0 + MM_BM - 1) return;                  // output tile entirely above the diagonal: never read
+    const int zo = (int)blockIdx.z / a.batch_inner, zi = (int)blockIdx.z - zo * a.batch_inner;
+    const unsigned short* Ab = (const unsigned short*)a.A + (size_t)zo * a.sA + (size_t)zi * a.sA2;
+    const unsigned short* Bb = (const unsigned short*)a.B + (size_t)zo * a.sB + (size_t)(zi / a.b_inner_div) * a.sB2;
+    const size_t a_bytes = ((size_t)(a.M - 1) * a.lda + a.K) * 2, b_bytes = PACKED_B ? (size_t)((a.N + 15) / 16) * (a.K / 32) * 1024 : ((size_t)(a.N - 1) * a.ldb + a.K) * 2;
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)(a_bytes > 0x7fffffffu ? 0x7fffffffu : a_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)(b_bytes > 0x7fffffffu ? 0x7fffffffu : b_bytes), 0x00020000);
+
+    // K range of this tile: a causal product with a lower-triangular A (P . V) or a lower-triangular C (dV = P^T . dO
+    // handled by the caller through transposes) only needs k up to the tile's last row
+    const int k_end = (a.causal == 2) ? min(a.K, m0 + MM_BM) : a.K;
+    const int kt0 = (a.causal == 3) ? m0 / MM_BK : 0;                  // an upper-triangular A: nothing before the tile's first row
+    const int KT = (k_end + MM_BK - 1) / MM_BK - kt0;
+
+    // ---- staging: 4 pieces of 16 bytes per thread and operand ----
+    // piece c = tid + NTHR * i of an operand's step: row c >> 3, chunk c & 7 (a packed B: the 64 pieces of a 1 KiB tile
+    // in storage order); everything about a piece but its k0 is fixed, and cheap enough to recompute from c
+    unsigned a_src[PA], b_src[PB];        // byte offset of the piece at k0 = 0 (0xFFFFFFFF: row out of range)
+    unsigned a_dst[PA], b_dst[PB];        // its place in an LDS buffer
+    int a_k[PA], b_k[PB];                 // its first k inside a step
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int c = tid + NTHR * i, row = c >> 3, ch = c & 7;
+        a_k[i] = 8 * ch; a_dst[i] = mm_lds_off(row, ch);
+        a_src[i] = (m0 + row < a.M) ? (unsigned)(((size_t)(m0 + row) * a.lda + 8 * ch) * 2) : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int c = tid + NTHR * i;
+        if (PACKED_B) {
+            const int r = c & 15, g = (c >> 4) & 3, ktl = (c >> 6) & 1, rgl = c >> 7, row = rgl * 16 + r, ch = ktl * 4 + g;
+            b_k[i] = 8 * ch; b_dst[i] = A_BYTES + mm_lds_off(row, ch);
+            b_src[i] = (n0 + row < a.N) ? (unsigned)((((size_t)((n0 >> 4) + rgl) * (a.K >> 5) + ktl) * 512 + g * 128 + r * 8) * 2) : 0xFFFFFFFFu;
+        } else {
+            const int row = c >> 3, ch = c & 7;
+            b_k[i] = 8 * ch; b_dst[i] = A_BYTES + mm_lds_off(row, ch);
+            b_src[i] = (n0 + row < a.N) ? (unsigned)(((size_t)(n0 + row) * a.ldb + 8 * ch) * 2) : 0xFFFFFFFFu;
+        }
+    }
+    kg_u4 sa[PA], sb[PB];
+    auto stage_load = [&](int kt) {
+        const int k0 = (kt0 + kt) * MM_BK;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const bool ok = (k0 + a_k[i] < k_end) && a_src[i] != 0xFFFFFFFFu;
+            sa[i] = __builtin_amdgcn_raw_buffer_load_b128(ar, ok ? a_src[i] + (unsigned)(k0 * 2) : 0xFFFFFFFFu, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const bool ok = (k0 + b_k[i] < k_end) && b_src[i] != 0xFFFFFFFFu;
+            const unsigned boff = PACKED_B ? b_src[i] + (unsigned)((k0 >> 5) * 1024) : b_src[i] + (unsigned)(k0 * 2);
+            sb[i] = __builtin_amdgcn_raw_buffer_load_b128(br, ok ? boff : 0xFFFFFFFFu, 0, 0);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        char* l = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) *(kg_u4*)(l + a_dst[i]) = sa[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) *(kg_u4*)(l + b_dst[i]) = sb[i];
+    };
+
+    kg_f4 acc[TM][TN];                    // [m tile][n tile]: lane holds C[m = 16 mi + fr][n = 16 ni + 4 fg + e]
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = kg_f4{0.f, 0.f, 0.f, 0.f};
+
+    if (KT > 0) { stage_load(0); stage_store(0); }
+    if (KT > 1) stage_load(1);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const char* la = smem + (kt & 1) * STAGE + wr * (BM / WM) * 128;
+        const char* lb = smem + (kt & 1) * STAGE + A_BYTES + wc * (BN / WN) * 128;
+#pragma unroll
+        for (int ks = 0; ks < MM_BK / 32; ++ks) {
+            kg_u4 fa[TM], fb[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *(const kg_u4*)(lb + mm_lds_off(16 * j + fr, 4 * ks + fg));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *(const kg_u4*)(la + mm_lds_off(16 * i + fr, 4 * ks + fg));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma(fb[j], fa[i], acc[i][j]);       // D[n = 4 fg + e][m = fr]
+        }
+        if (kt + 1 < KT) stage_store((kt + 1) & 1);       // the other buffer: last read in step kt - 1, which every wave has left
+        if (kt + 2 < KT) stage_load(kt + 2);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    const size_t cb = (size_t)zo * a.sC + (size_t)zi * a.sC2;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wr * (BM / WM) + 16 * i + fr;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * (BN / WN) + 16 * j + 4 * fg;
+            if (n >= a.N) continue;
+            kg_f4 v = acc[i][j];
+            if (a.alpha != 1.0f) v = v * a.alpha;
+            if (OUT_F32) {
+                float* dst = (float*)a.C + cb + (size_t)m * a.ldc + n;
+                if (n + 3 < a.N && ((a.ldc | n) & 3) == 0) *(kg_f4*)dst = v;
+                else for (int e = 0; e < 4 && n + e < a.N; ++e) dst[e] = v[e];
+            } else {
+                unsigned short* dst = (unsigned short*)a.C + cb + (size_t)m * a.ldc + n;
+                const unsigned short h0 = T::from_f(v[0]), h1 = T::from_f(v[1]), h2 = T::from_f(v[2]), h3 = T::from_f(v[3]);
+                if (n + 3 < a.N && ((a.ldc | n) & 3) == 0) *(unsigned long long*)dst = (unsigned long long)h0 | ((unsigned long long)h1 << 16) | ((unsigned long long)h2 << 32) | ((unsigned long long)h3 << 48);
+                else { const unsigned short h[4] = {h0, h1, h2, h3}; for (int e = 0; e < 4 && n + e < a.N; ++e) dst[e] = h[e]; }
+            }
+        }
+    }
+}
+
+static int g_mm_ncu = 256;
+template <int DT, int BM, int BN, int WM, int WN, bool PACKED_B>
+static void mm_launch_tile(const KgMmArgs& a, hipStream_t st) {
+    const size_t smem = 2 * (size_t)(BM + BN) * MM_BK * 2;
+    const dim3 grid(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN), 1, a.batch), block(WM * WN * 64);
+    if (a.out_f32) hipLaunchKernelGGL((kg_mm_kernel<DT, BM, BN, WM, WN, PACKED_B, true>), grid, block, smem, st, a);
+    else hipLaunchKernelGGL((kg_mm_kernel<DT, BM, BN, WM, WN, PACKED_B, false>), grid, block, smem, st, a);
+}
+template <int DT, bool PACKED_B>
+static void mm_launch(const KgMmArgs& a, hipStream_t st) {
+    // the large tile once it fills the chip (and always when forced: a.tile == 2; a.tile == 1 forces the small one)
+    const long big_tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.batch;
+    const bool big = a.tile == 2 || (a.tile == 0 && big_tiles >= g_mm_ncu);
+    if (big) mm_launch_tile<DT, 256, 256, 2, 4, PACKED_B>(a, st);
+    else mm_launch_tile<DT, 128, 128, 2, 2, PACKED_B>(a, st);
+}
+
+int kg_launch_mm(const KgMmArgs& a, int dtype, hipStream_t st) {
+    if (!a.A || !a.B || !a.C || a.M < 1 || a.N < 1 || a.K < 8 || (a.K & 7) || a.batch < 1 || a.batch > 65535) return -1;
+    if ((a.lda & 7) || (!a.b_packed && (a.ldb & 7)) || (a.sA & 7) || (a.sB & 7)) return -1;      // 16-byte pieces
+    if (a.b_packed && ((a.K & 31) || a.batch != 1)) return -1;
+    if (a.causal < 0 || a.causal > 3) return -1;
+    if (a.batch_inner < 1 || a.batch % a.batch_inner || a.b_inner_div < 1 || (a.sA2 & 7) || (a.sB2 & 7)) return -1;
+    if (a.tile < 0 || a.tile > 2) return -1;
+    if (dtype == KG_F16) { if (a.b_packed) mm_launch<KG_F16, true>(a, st); else mm_launch<KG_F16, false>(a, st); }
+    else { if (a.b_packed) mm_launch<KG_BF16, true>(a, st); else mm_launch<KG_BF16, false>(a, st); }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int DT, bool P, bool F> static void mm_attr() {
+    (void)hipFuncSetAttribute((const void*)kg_mm_kernel<DT, 128, 128, 2, 2, P, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * MM_BK * 2);
+    (void)hipFuncSetAttribute((const void*)kg_mm_kernel<DT, 256, 256, 2, 4, P, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * MM_BK * 2);
+}
+void kg_mm_init() {
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) g_mm_ncu = ncu;
+    mm_attr<KG_F16, false, false>(); mm_attr<KG_F16, false, true>(); mm_attr<KG_F16, true, false>(); mm_attr<KG_F16, true, true>();
+    mm_attr<KG_BF16, false, false>(); mm_attr<KG_BF16, false, true>(); mm_attr<KG_BF16, true, false>(); mm_attr<KG_BF16, true, true>();
+    (void)hipGetLastError();
+}
+
+// out[b][c][r] = in[b][r][c] for 16-bit elements: 64 x 64 tiles through LDS, both sides in whole lines
+__global__ void __launch_bounds__(256) kg_transpose16_kernel(const unsigned short* in, unsigned short* out, int R, int Cn, long long ld_in, long long ld_out,
+                                                             long long s_in, long long s_out) {
+    __shared__ unsigned short t[64][66];
+    const unsigned short* ib = in + (size_t)blockIdx.z * s_in;
+    unsigned short* ob = out + (size_t)blockIdx.z * s_out;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        t[i][tx] = (r < R && c < Cn) ? ib[(size_t)r * ld_in + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < Cn && r < R) ob[(size_t)c * ld_out + r] = t[tx][i];
+    }
+}
+int kg_launch_transpose16(const void* in, void* out, int R, int Cn, long long ld_in, long long ld_out, int batch, long long s_in, long long s_out, hipStream_t st) {
+    if (!in || !out || R < 1 || Cn < 1 || batch < 1 || batch > 65535) return -1;
+    const dim3 grid((Cn + 63) / 64, (R + 63) / 64, batch);
+    hipLaunchKernelGGL(kg_transpose16_kernel, grid, dim3(256), 0, st, (const unsigned short*)in, (unsigned short*)out, R, Cn, ld_in, ld_out, s_in, s_out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

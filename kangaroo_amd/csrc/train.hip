@@ -276,13 +276,13 @@ __global__ void __launch_bounds__(TB) softmax_bwd_kernel(const unsigned short* p
 //   rank = number of out-logits above the out-logit of the target's argmax (lowest index on ties): the target token is
 //   among the top k predictions iff rank < k (train.py:298-305); -1 for rows outside the loss mask.
 template <int DT, int W>
-__global__ void __launch_bounds__(TB) softce_kernel(unsigned short* o, const unsigned short* t, const int* loss_mask, int V, float grad_scale,
+__global__ void __launch_bounds__(TB) softce_kernel(unsigned short* o, const unsigned short* t, const int* loss_mask, int V, size_t ld, float grad_scale,
                                                      float* row_loss, float* row_acc, int* row_rank) {
     typedef KgT<DT> T;
     __shared__ float red[4];
     const size_t row = blockIdx.x;
-    unsigned short* orow = o + row * V;
-    const unsigned short* trow = t + row * V;
+    unsigned short* orow = o + row * ld;
+    const unsigned short* trow = t + row * ld;
     if (loss_mask[row] == 0) {
         const float z[W] = {};
         for (int c = threadIdx.x; c < V / W; c += TB) storew<DT, W>(orow + W * c, z);
@@ -360,6 +360,18 @@ __global__ void adamw_kernel(float* p, float* m, float* v, const void* grad, flo
     if (p16) p16[i] = KgT<WDT>::from_f(w);
 }
 
+// y[i] = round16(y[i] + x[i]): the residual add of kangaroo/adapter.py:304 on stored 16-bit tensors
+template <int DT>
+__global__ void add16_kernel(unsigned short* y, const unsigned short* x, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const kg_us8 a = __builtin_bit_cast(kg_us8, ((const kg_u4*)y)[i]), b = __builtin_bit_cast(kg_us8, ((const kg_u4*)x)[i]);
+    kg_us8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = KgT<DT>::from_f(KgT<DT>::to_f(a[e]) + KgT<DT>::to_f(b[e]));
+    ((kg_u4*)y)[i] = __builtin_bit_cast(kg_u4, o);
+}
+
 int done(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { kg_set_error(what, e); return -2; }
@@ -429,16 +441,26 @@ extern "C" int kg_train_softmax_bwd(int dtype, const void* probs, void* dprobs, 
     return done("kg_train_softmax_bwd");
 }
 
-extern "C" int kg_train_softce(int dtype, void* logits_out, const void* logits_tgt, const int* loss_mask, int rows, int vocab, float grad_scale,
+extern "C" int kg_train_softce(int dtype, void* logits_out, const void* logits_tgt, const int* loss_mask, int rows, int vocab, long long row_stride, float grad_scale,
                                float* row_loss, float* row_acc, int* row_rank, void* stream) {
-    if (!logits_out || !logits_tgt || !loss_mask || !row_loss || !row_acc || rows < 1 || vocab < 1 || vocab >= (1 << 24)) return -1;
+    if (!logits_out || !logits_tgt || !loss_mask || !row_loss || !row_acc || rows < 1 || vocab < 1 || vocab >= (1 << 24) || row_stride < vocab) return -1;
     hipStream_t st = (hipStream_t)stream;
-    const bool wide = (vocab & 7) == 0 && (((uintptr_t)logits_out | (uintptr_t)logits_tgt) & 15) == 0;
-#define KG_SOFTCE(D, W) hipLaunchKernelGGL((softce_kernel<D, W>), dim3(rows), dim3(TB), 0, st, (unsigned short*)logits_out, (const unsigned short*)logits_tgt, loss_mask, vocab, grad_scale, row_loss, row_acc, row_rank)
+    const bool wide = ((vocab | row_stride) & 7) == 0 && (((uintptr_t)logits_out | (uintptr_t)logits_tgt) & 15) == 0;
+#define KG_SOFTCE(D, W) hipLaunchKernelGGL((softce_kernel<D, W>), dim3(rows), dim3(TB), 0, st, (unsigned short*)logits_out, (const unsigned short*)logits_tgt, loss_mask, vocab, (size_t)row_stride, grad_scale, row_loss, row_acc, row_rank)
     if (dtype == KG_F16) { if (wide) KG_SOFTCE(KG_F16, 8); else KG_SOFTCE(KG_F16, 1); }
     else { if (wide) KG_SOFTCE(KG_BF16, 8); else KG_SOFTCE(KG_BF16, 1); }
 #undef KG_SOFTCE
     return done("kg_train_softce");
+}
+
+extern "C" int kg_train_add(int dtype, void* y, const void* x, long long n, void* stream) {
+    if (!y || !x || n < 8 || (n & 7) || (((uintptr_t)y | (uintptr_t)x) & 15)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n8 = (size_t)n / 8;
+    const dim3 grid((unsigned)((n8 + 255) / 256));
+    if (dtype == KG_F16) hipLaunchKernelGGL(add16_kernel<KG_F16>, grid, dim3(256), 0, st, (unsigned short*)y, (const unsigned short*)x, n8);
+    else hipLaunchKernelGGL(add16_kernel<KG_BF16>, grid, dim3(256), 0, st, (unsigned short*)y, (const unsigned short*)x, n8);
+    return done("kg_train_add");
 }
 
 // grad_dtype: KG_F16 / KG_BF16 / 2 (fp32); copy_dtype: KG_F16 / KG_BF16 (p16 may be NULL); step is 1-based.

@@ -4,16 +4,19 @@ The adapter is one attention-only decoder layer plus the final RMSNorm (kangaroo
 that the frozen lm_head on its output matches the head on the full model's last hidden state (soft-label cross
 entropy, train.py:265-278).  Per step and rank:
 
-    forward   RMSNorm -> q/k/v GEMMs -> RoPE -> scores GEMM -> masked softmax -> context GEMM -> o_proj GEMM
-              -> residual -> RMSNorm -> two lm_head GEMMs (adapter output, target)
+    forward   RMSNorm -> q/k/v products -> RoPE -> scores -> masked softmax -> context -> o_proj
+              -> residual -> RMSNorm -> two lm_head products (adapter output, target)
     loss      one fused pass over both logit rows: log-softmax, cross entropy, expected acceptance, dlogits
-    backward  the transposed GEMMs, softmax / RoPE / RMSNorm backward kernels
+    backward  the transposed products, softmax / RoPE / RMSNorm backward kernels
     update    gradient all-reduce over the data-parallel group (RCCL), clip by value, AdamW, 16-bit weight copy
 
-The GEMMs run over batch x sequence rows (thousands): compute-bound library calls (`torch.matmul` = hipBLASLt).
-Everything between them is a hand-written kernel of libkangaroo_hip.so (csrc/train.hip).  With 288 GB of HBM the
-step materialises the attention probabilities [B, H, S, S] and both logit matrices [B*S, V] in 16 bit instead of
-recomputing them (4 x 2048 tokens at the 7B shape: 1 GiB + 2 x 0.5 GiB).
+Every matrix product is kg_matmul_nt (csrc/mm.hip: C = A . B^T on the matrix cores, 256 x 256 tiles), the heads of
+[B, S, H, hd] tensors addressed in place (kg_matmul_nt_heads), causal products skipping the empty half; a product
+whose contraction index is not contiguous in one operand first transposes that operand (kg_transpose16: the weights
+once per step, the head once for good, activations for the weight gradients).  Everything between the products is a
+hand-written kernel of csrc/train.hip.  With 288 GB of HBM the step materialises the attention probabilities
+[B, H, S, S] and both logit matrices [B*S, V] in 16 bit instead of recomputing them (4 x 2048 tokens at the 7B shape:
+1 GiB + 2 x 0.5 GiB).  torch only allocates.
 
 Mixed precision as the reference runs it (accelerate, fp16 autocast, train.py:46): fp32 master weights and
 optimizer state, 16-bit activations and GEMM inputs, fp32 statistics; gradients of activations are carried in 16
@@ -152,6 +155,9 @@ class AdapterTrainer:
         self.v = {k: torch.zeros_like(v) for k, v in self.p.items()}
         self.w16 = {k: v.to(dtype) for k, v in self.p.items() if v.dim() == 2}
         self.head16 = head_weight.detach().to(self.device, dtype).contiguous()
+        if self.head16.shape[0] % 8:                                                  # zero rows up to a multiple of 8: their logits are exact zeros the loss never reads
+            self.head16 = torch.nn.functional.pad(self.head16, (0, 0, 0, 8 - self.head16.shape[0] % 8)).contiguous()
+        self.head16_t = self._transpose(self.head16)                      # [d, V]: the frozen head for dhn = dlogits . W
         cos, sin = rope_tables(shape.head_dim, shape.max_position_embeddings, shape.rope_base, device=self.device)
         self.cos, self.sin = cos.contiguous(), sin.contiguous()
 
@@ -182,78 +188,139 @@ class AdapterTrainer:
     def _rope(self, x, rows, S, n_heads, inverse: bool):
         _lib.check(self.lib.kg_train_rope(self.dt, self._p(x), rows, S, n_heads, self.shape.head_dim, self._p(self.cos), self._p(self.sin), 1 if inverse else 0, self._st()), "kg_train_rope")
 
+    def _mm(self, A, B, out_f32: bool = False):
+        """A [M, K] . B [N, K]^T -> [M, N] (row strides may exceed K: views of wider tensors)."""
+        M, K = A.shape
+        N = B.shape[0]
+        assert B.shape[1] == K and A.stride(1) == 1 and B.stride(1) == 1
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else self.dtype, device=self.device)
+        _lib.check(self.lib.kg_matmul_nt(self.dt, self._p(A), self._p(B), self._p(out), M, N, K, A.stride(0), B.stride(0), N,
+                                         1, 0, 0, 0, 0, 1 if out_f32 else 0, 0, 1.0, self._st()), "kg_matmul_nt")
+        return out
+
+    def _transpose(self, x, batch: int = 1):
+        """[batch, R, C] (or [R, C]) -> [batch, C, R], contiguous."""
+        x = x.contiguous()
+        R, Cn = x.shape[-2], x.shape[-1]
+        out = torch.empty(x.shape[:-2] + (Cn, R), dtype=x.dtype, device=x.device)
+        _lib.check(self.lib.kg_transpose16(self._p(x), self._p(out), R, Cn, Cn, R, batch, R * Cn, R * Cn, self._st()), "kg_transpose16")
+        return out
+
     # -- one step --------------------------------------------------------------------
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, float]:
         sh, dt, dev = self.shape, self.dtype, self.device
         H, Hkv, hd, d, V = sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim, sh.hidden_size, sh.vocab_size
+        if hd % 8 or d % 8:
+            raise ValueError("head_dim and hidden_size must be multiples of 8 (16-byte rows)")
+        Vp = self.head16.shape[0]                                                    # vocabulary rounded up to whole 16-byte pieces
         x3 = batch["hidden_states_early"].to(dev, dt)
-        B, S, _ = x3.shape
-        if S > sh.max_position_embeddings:
+        tgt3 = batch["target"].to(dev, dt)
+        key_mask = batch["attention_mask"].to(dev, torch.int32)
+        loss_mask = batch["loss_mask"].to(dev, torch.int32)
+        B, S0, _ = x3.shape
+        if S0 > sh.max_position_embeddings:
             raise ValueError("sequence longer than max_position_embeddings")
+        # The collator pads to the longest sample with zero rows and zero masks (train.py:151-185); padding a little
+        # further, to a multiple of 8 positions, changes no position that counts and makes every row of the
+        # [S, S] matrices a whole number of 16-byte pieces.
+        S = (S0 + 7) // 8 * 8
+        if S != S0:
+            pad = S - S0
+            x3 = torch.nn.functional.pad(x3, (0, 0, 0, pad)); tgt3 = torch.nn.functional.pad(tgt3, (0, 0, 0, pad))
+            key_mask = torch.nn.functional.pad(key_mask, (0, pad)); loss_mask = torch.nn.functional.pad(loss_mask, (0, pad))
         R = B * S
         x = x3.reshape(R, d).contiguous()
-        tgt = batch["target"].to(dev, dt).reshape(R, d).contiguous()
-        key_mask = batch["attention_mask"].to(dev, torch.int32).contiguous()
-        loss_mask = batch["loss_mask"].to(dev, torch.int32).reshape(R).contiguous()
+        tgt = tgt3.reshape(R, d).contiguous()
+        key_mask = key_mask.contiguous()
+        loss_mask = loss_mask.reshape(R).contiguous()
         n_loss = int(loss_mask.sum().item())
         if n_loss == 0:
             raise ValueError("the batch has no position with loss_mask == 1")
         W = self.w16
         scale = 1.0 / math.sqrt(hd)
         rep = H // Hkv
+        qd, kvd = H * hd, Hkv * hd
+
+        def heads(A, lda, sA, sA2, Bm, ldb, sB, sB2, out, ldc, sC, sC2, M, N, K, causal):
+            # one product per (b, h): A / out at b * sX + h * sX2, B at b * sB + (h // rep) * sB2 (elements)
+            _lib.check(self.lib.kg_matmul_nt_heads(self.dt, self._p(A), self._p(Bm), self._p(out), M, N, K, lda, ldb, ldc, B * H, sA, sB, sC,
+                                                   H, sA2, sB2, sC2, rep, 0, 0, causal, 1.0, self._st()), "kg_matmul_nt_heads")
 
         # ---- forward (kangaroo/adapter.py:378-460) ----
         xn, rstd1 = self._rmsnorm_fwd(x, self.p["input_layernorm"])
-        q = xn @ W["q_proj"].t()
-        k = xn @ W["k_proj"].t()
-        v = xn @ W["v_proj"].t()
+        q = self._mm(xn, W["q_proj"])                                                # [R, H hd]: heads are read in place below
+        k = self._mm(xn, W["k_proj"])
+        v = self._mm(xn, W["v_proj"])
         self._rope(q, R, S, H, False)
         self._rope(k, R, S, Hkv, False)
-        qh = q.view(B, S, H, hd).transpose(1, 2)
-        kh = k.view(B, S, Hkv, hd).transpose(1, 2)
-        vh = v.view(B, S, Hkv, hd).transpose(1, 2)
-        if rep > 1:
-            kh = kh.repeat_interleave(rep, dim=1)
-            vh = vh.repeat_interleave(rep, dim=1)
-        probs = torch.matmul(qh, kh.transpose(2, 3)).contiguous()                      # scores, then probabilities in place
+        # scores[b, h] = q[b, :, h] . k[b, :, h // rep]^T over the causal half, then the probabilities in place
+        probs = torch.empty((B, H, S, S), dtype=dt, device=dev)
+        heads(q, qd, S * qd, hd, k, kvd, S * kvd, hd, probs, S, H * S * S, S * S, S, S, hd, 1)
         _lib.check(self.lib.kg_train_softmax_fwd(self.dt, self._p(probs), self._p(key_mask), B, H, S, scale, self._st()), "kg_train_softmax_fwd")
-        ctx = torch.matmul(probs, vh).transpose(1, 2).reshape(R, H * hd)
-        h = x + ctx @ W["o_proj"].t()
+        # ctx[b, :, h] = probs[b, h] . v[b, :, h // rep]: the contraction runs over the keys, so V goes in transposed
+        vt = self._transpose(v.view(B, S, kvd), B)                                   # [B, Hkv hd, S]
+        ctx = torch.empty((R, qd), dtype=dt, device=dev)
+        heads(probs, S, H * S * S, S * S, vt, S, kvd * S, hd * S, ctx, qd, S * qd, hd, S, hd, S, 2)
+        h = self._mm(ctx, W["o_proj"])
+        _lib.check(self.lib.kg_train_add(self.dt, self._p(h), self._p(x), h.numel(), self._st()), "kg_train_add")     # h = x + o_proj(ctx)
         hn, rstd2 = self._rmsnorm_fwd(h, self.p["norm"])
 
         # ---- loss through the frozen head (train.py:265-279) ----
-        logits = hn @ self.head16.t()                                                # becomes dlogits
-        tlogits = tgt @ self.head16.t()
+        logits = self._mm(hn, self.head16)                                           # becomes dlogits
+        tlogits = self._mm(tgt, self.head16)
         row_loss = torch.empty(R, dtype=torch.float32, device=dev)
         row_acc = torch.empty(R, dtype=torch.float32, device=dev)
         row_rank = torch.empty(R, dtype=torch.int32, device=dev)
-        _lib.check(self.lib.kg_train_softce(self.dt, self._p(logits), self._p(tlogits), self._p(loss_mask), R, V, self.loss_scale / n_loss,
+        _lib.check(self.lib.kg_train_softce(self.dt, self._p(logits), self._p(tlogits), self._p(loss_mask), R, V, Vp, self.loss_scale / n_loss,
                                             self._p(row_loss), self._p(row_acc), self._p(row_rank), self._st()), "kg_train_softce")
         del tlogits
 
-        # ---- backward ----
-        dhn = logits @ self.head16
+        # ---- backward: every product as A . B^T, the operand whose contraction index is strided transposed first ----
+        dhn = self._mm(logits, self.head16_t)                                        # [R, d] = dlogits . W
         del logits
         dh, dg2 = self._rmsnorm_bwd(dhn, h, self.p["norm"], rstd2, True)
-        g_o = dh.t() @ ctx                                                           # [d, H*hd]
+        dh_t = self._transpose(dh)                                                   # [d, R]
+        g_o = self._mm(dh_t, self._transpose(ctx), out_f32=True)                     # [d, H hd] = dh^T . ctx, summed over the rows in fp32
         (g_o32, dg2s) = self.sync.start([g_o, dg2])
-        dctx = (dh @ W["o_proj"]).view(B, S, H, hd).transpose(1, 2)
-        dprobs = torch.matmul(dctx, vh.transpose(2, 3)).contiguous()
-        dvh = torch.matmul(probs.transpose(2, 3), dctx)                              # [B, H, S, hd]
+        dctx = self._mm(dh, self._transpose(W["o_proj"]))                            # [R, H hd] = dh . Wo
+        # dprobs[b, h] = dctx[b, :, h] . v[b, :, h // rep]^T (causal half), then dscores in place
+        dprobs = torch.empty((B, H, S, S), dtype=dt, device=dev)
+        heads(dctx, qd, S * qd, hd, v, kvd, S * kvd, hd, dprobs, S, H * S * S, S * S, S, S, hd, 1)
+        # dv[b, :, h] = probs[b, h]^T . dctx[b, :, h]: rows = keys, contraction over the queries at or after the key
+        probs_t = self._transpose(probs.view(B * H, S, S), B * H)
+        dctx_t = self._transpose(dctx.view(B, S, qd), B)                             # [B, H hd, S]
+        dvh = torch.empty((B, S, H, hd), dtype=dt, device=dev)
+        _lib.check(self.lib.kg_matmul_nt_heads(self.dt, self._p(probs_t), self._p(dctx_t), self._p(dvh), S, hd, S, S, S, qd, B * H, H * S * S, qd * S, S * qd,
+                                               H, S * S, hd * S, hd, 1, 0, 0, 3, 1.0, self._st()), "kg_matmul_nt_heads")
+        del probs_t
         _lib.check(self.lib.kg_train_softmax_bwd(self.dt, self._p(probs), self._p(dprobs), B, H, S, scale, self._st()), "kg_train_softmax_bwd")
-        dqh = torch.matmul(dprobs, kh)
-        dkh = torch.matmul(dprobs.transpose(2, 3), qh)
-        del probs, dprobs
-        if rep > 1:
-            dkh = dkh.view(B, Hkv, rep, S, hd).sum(dim=2)
-            dvh = dvh.view(B, Hkv, rep, S, hd).sum(dim=2)
-        dq = dqh.transpose(1, 2).reshape(R, H * hd).contiguous()
-        dk = dkh.transpose(1, 2).reshape(R, Hkv * hd).contiguous()
-        dv = dvh.transpose(1, 2).reshape(R, Hkv * hd).contiguous()
+        del probs
+        # dq[b, :, h] = dscores[b, h] . k[b, :, h // rep] (keys contracted: K transposed); dk[b, :, h] = dscores[b, h]^T . q[b, :, h]
+        kt = self._transpose(k.view(B, S, kvd), B)                                   # [B, Hkv hd, S]
+        dq = torch.empty((R, qd), dtype=dt, device=dev)
+        heads(dprobs, S, H * S * S, S * S, kt, S, kvd * S, hd * S, dq, qd, S * qd, hd, S, hd, S, 2)
+        ds_t = self._transpose(dprobs.view(B * H, S, S), B * H)
+        del dprobs
+        q_t = self._transpose(q.view(B, S, qd), B)                                   # [B, H hd, S]
+        dkh = torch.empty((B, S, H, hd), dtype=dt, device=dev)
+        _lib.check(self.lib.kg_matmul_nt_heads(self.dt, self._p(ds_t), self._p(q_t), self._p(dkh), S, hd, S, S, S, qd, B * H, H * S * S, qd * S, S * qd,
+                                               H, S * S, hd * S, hd, 1, 0, 0, 3, 1.0, self._st()), "kg_matmul_nt_heads")
+        del ds_t
+        if rep > 1:                                                                  # query heads that shared a key / value head
+            dk = dkh.view(B, S, Hkv, rep, hd).sum(dim=3).reshape(R, kvd).contiguous()
+            dv = dvh.view(B, S, Hkv, rep, hd).sum(dim=3).reshape(R, kvd).contiguous()
+        else:
+            dk, dv = dkh.view(R, kvd), dvh.view(R, kvd)
         self._rope(dq, R, S, H, True)
         self._rope(dk, R, S, Hkv, True)
-        g_q, g_k, g_v = dq.t() @ xn, dk.t() @ xn, dv.t() @ xn
-        dxn = dq @ W["q_proj"] + dk @ W["k_proj"] + dv @ W["v_proj"]
+        xn_t = self._transpose(xn)                                                   # [d, R]
+        g_q = self._mm(self._transpose(dq), xn_t, out_f32=True)                      # [H hd, d] = dq^T . xn
+        g_k = self._mm(self._transpose(dk), xn_t, out_f32=True)
+        g_v = self._mm(self._transpose(dv), xn_t, out_f32=True)
+        dxn = self._mm(dq, self._transpose(W["q_proj"]))                             # [R, d] = dq . Wq + dk . Wk + dv . Wv
+        for dd, key in ((dk, "k_proj"), (dv, "v_proj")):
+            t = self._mm(dd, self._transpose(W[key]))
+            _lib.check(self.lib.kg_train_add(self.dt, self._p(dxn), self._p(t), dxn.numel(), self._st()), "kg_train_add")
         _, dg1 = self._rmsnorm_bwd(dxn, x, self.p["input_layernorm"], rstd1, False)
         (g_q32, g_k32, g_v32, dg1s) = self.sync.start([g_q, g_k, g_v, dg1])
         self.sync.finish()
@@ -271,7 +338,7 @@ class AdapterTrainer:
         self.last_grads = {k: g * inv_scale for k, g in grads.items()}                 # unscaled, before clipping (tests, logging)
         sums = torch.stack([row_loss.sum(), row_acc.sum()] + [((row_rank >= 0) & (row_rank < k)).sum().float() for k in (1, 2, 3)]).tolist()
         # top-k counts as train.py:298-309 accumulates them (the target token = argmax of the target head)
-        return {"loss": sums[0] / n_loss, "prob_acc": sums[1] / n_loss, "lr": lr, "tokens": R, "loss_positions": n_loss,
+        return {"loss": sums[0] / n_loss, "prob_acc": sums[1] / n_loss, "lr": lr, "tokens": B * S0, "loss_positions": n_loss,
                 "top1_correct": int(sums[2]), "top2_correct": int(sums[3]), "top3_correct": int(sums[4])}
 
     def state_dict(self, dtype=None) -> Dict[str, torch.Tensor]:

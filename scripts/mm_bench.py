@@ -1,0 +1,80 @@
+"""kg_matmul_nt against torch.matmul (hipBLASLt): results and time at the shapes of the adapter training step and
+the prompt pass.  python scripts/mm_bench.py [--quick]"""
+import ctypes as C, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kangaroo_amd import _lib
+from kangaroo_amd.packing import pack_weight
+
+lib = _lib.lib()
+dev = "cuda"
+
+
+def mm(A, B, out_f32=False, packed=None, causal=0, alpha=1.0, N=None):
+    """A [.., M, K], B [.., N, K] (or packed, with N given) -> C [.., M, N]"""
+    dt = _lib.DT_F16 if A.dtype == torch.float16 else _lib.DT_BF16
+    batch = A.shape[0] if A.dim() == 3 else 1
+    M, K = A.shape[-2], A.shape[-1]
+    N = N if packed is not None else B.shape[-2]
+    Cc = torch.empty((batch, M, N) if A.dim() == 3 else (M, N), dtype=torch.float32 if out_f32 else A.dtype, device=A.device)
+    Bp = packed if packed is not None else B
+    _lib.check(lib.kg_matmul_nt(dt, A.data_ptr(), Bp.data_ptr(), Cc.data_ptr(), M, N, K, A.stride(-2), 0 if packed is not None else B.stride(-2), N,
+                                batch, A.stride(0) if A.dim() == 3 else 0, B.stride(0) if (packed is None and B.dim() == 3) else 0, M * N if A.dim() == 3 else 0,
+                                1 if packed is not None else 0, 1 if out_f32 else 0, causal, alpha, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "kg_matmul_nt")
+    return Cc
+
+
+def timeit(f, n=10):
+    f(); torch.cuda.synchronize()
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(n):
+        f()
+    t1.record(); torch.cuda.synchronize()
+    return t0.elapsed_time(t1) / n
+
+
+g = torch.Generator(device=dev).manual_seed(0)
+# ---- results ----
+for dt in (torch.float16, torch.bfloat16):
+    for (M, N, K) in ((128, 128, 64), (200, 136, 72), (1000, 520, 4096), (77, 4096, 256), (257, 129, 8)):
+        A = torch.randn(M, K, device=dev, generator=g).to(dt); B = torch.randn(N, K, device=dev, generator=g).to(dt)
+        ref = A.float() @ B.float().T
+        for f32 in (False, True):
+            got = mm(A, B, out_f32=f32).float()
+            err = float((got - ref).abs().max()) / float(ref.abs().max())
+            assert err < (1e-5 if f32 else (2e-3 if dt == torch.float16 else 1.2e-2)), (dt, M, N, K, f32, err)
+    W = torch.randn(528, 4096, device=dev, generator=g).to(dt); X = torch.randn(300, 4096, device=dev, generator=g).to(dt)
+    got = mm(X, None, out_f32=True, packed=pack_weight(W), N=528)
+    assert float((got - X.float() @ W.float().T).abs().max()) < 1e-4 * 4096 ** 0.5 * 4
+    assert torch.equal(got, mm(X, W, out_f32=True))          # same products, same order: the packed layout only changes addresses
+    # batched, causal
+    Q = torch.randn(6, 300, 128, device=dev, generator=g).to(dt); Kk = torch.randn(6, 300, 128, device=dev, generator=g).to(dt)
+    S = mm(Q, Kk, out_f32=True, causal=1, alpha=0.25)
+    ref = 0.25 * (Q.float() @ Kk.float().transpose(1, 2))
+    mask = torch.ones(300, 300, device=dev).tril().bool()
+    assert float(((S - ref) * mask).abs().max()) < 1e-3
+    P = (torch.rand(6, 300, 300, device=dev, generator=g) * mask).to(dt); Vt = torch.randn(6, 128, 300, device=dev, generator=g).to(dt)
+    pad = lambda t: torch.nn.functional.pad(t, (0, 4))         # K = 304: a multiple of 8
+    O = mm(pad(P), pad(Vt), out_f32=True, causal=2)
+    assert float((O - P.float() @ Vt.float().transpose(1, 2)).abs().max()) < 1e-3 * 300 ** 0.5
+    T_ = torch.randn(3, 70, 200, device=dev, generator=g).to(dt)
+    out = torch.empty(3, 200, 70, dtype=dt, device=dev)
+    _lib.check(lib.kg_transpose16(T_.data_ptr(), out.data_ptr(), 70, 200, 200, 70, 3, 70 * 200, 70 * 200, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "kg_transpose16")
+    assert torch.equal(out, T_.transpose(1, 2))
+print("results ok", flush=True)
+if "--quick" in sys.argv:
+    sys.exit(0)
+# ---- time ----
+dt = torch.float16
+for name, (M, N, K), batch in (("projection 8192x4096x4096", (8192, 4096, 4096), 1), ("head 8192x32000x4096", (8192, 32000, 4096), 1),
+                               ("dhn 8192x4096x32000", (8192, 4096, 32000), 1), ("weight grad 4096x4096x8192", (4096, 4096, 8192), 1),
+                               ("prefill 256 rows x (22016 x 4096)", (256, 22016, 4096), 1), ("prefill 640 rows x (22016 x 4096)", (640, 22016, 4096), 1),
+                               ("scores 128 x (2048x2048x128)", (2048, 2048, 128), 128), ("context 128 x (2048x128x2048)", (2048, 128, 2048), 128)):
+    shp = (batch, M, K) if batch > 1 else (M, K)
+    A = (torch.rand(shp, device=dev, generator=g) * 2 - 1).to(dt)
+    B = (torch.rand((batch, N, K) if batch > 1 else (N, K), device=dev, generator=g) * 2 - 1).to(dt)
+    fl = 2.0 * M * N * K * batch
+    t_own = timeit(lambda: mm(A, B))
+    t_lib = timeit(lambda: torch.matmul(A, B.transpose(-1, -2)))
+    print(f"{name:40s} own {t_own * 1e3:8.1f} us {fl / t_own / 1e9:7.0f} TFLOP/s   library {t_lib * 1e3:8.1f} us {fl / t_lib / 1e9:7.0f} TFLOP/s", flush=True)

@@ -124,7 +124,7 @@ def test_soft_label_cross_entropy(dtype, code, rows, V):
     d = o.clone()
     rl = torch.empty(rows, dtype=torch.float32, device=DEV); ra = torch.empty_like(rl)
     rk = torch.empty(rows, dtype=torch.int32, device=DEV)
-    _lib.check(lib.kg_train_softce(code, vp(d), vp(t), vp(lm), rows, V, gs, vp(rl), vp(ra), vp(rk), st()), "softce")
+    _lib.check(lib.kg_train_softce(code, vp(d), vp(t), vp(lm), rows, V, V, gs, vp(rl), vp(ra), vp(rk), st()), "softce")
     # rank of the target's argmax token among the out-logits (train.py:298-305 counts rank < k)
     tgt_tok = t.float().argmax(-1)
     want_rank = (o.float() > o.float().gather(1, tgt_tok[:, None])).sum(-1).to(torch.int32)
