@@ -320,10 +320,14 @@ int kg_bench_op(kg_session* s, int op, int rows, int iters, float* us_per_launch
  * the frozen head of train.py:265-273, and every product of their backward pass after a transpose of the operand whose
  * contraction index is not contiguous).  A, B: 16-bit (dtype), row strides lda / ldb in elements, multiples of 8, K a
  * multiple of 8; C: 16-bit, or fp32 when out_f32.  batch > 1: independent products at element strides sA / sB / sC
- * (attention heads).  b_packed: B is a decode-path weight in the packed tile layout (K % 32 == 0, batch 1).
+ * (attention heads).  b_packed 1: B is a decode-path weight in the packed tile layout (K % 32 == 0, batch 1);
+ * b_packed 2: B is given K-major, [K][N] with row stride ldb (C = alpha * A . B; N % 8 == 0): a product that contracts
+ * over the rows of a stored matrix needs no transposed copy of it.
  * causal 1: tiles of C entirely above the diagonal are neither computed nor written (scores of a causal attention);
  * causal 2: A is lower triangular, so K is walked only up to each tile's last row (probabilities times values);
- * causal 3: A is upper triangular, K is walked from each tile's first row on (transposed probabilities).
+ * causal 3: A is upper triangular, K is walked from each tile's first row on (transposed probabilities);
+ * causal 4 (K-major B only): row k of B has no entry beyond column k, K is walked from each tile's first column on
+ * (dV^T = dO^T . P over the queries at or after each key).
  * kg_matmul_nt_heads: the batch index z = zo * batch_inner + zi addresses A at zo * sA + zi * sA2, C likewise and B at
  * zo * sB + (zi / b_inner_div) * sB2: the heads of [batch, seq, heads, head_dim] tensors read in place, b_inner_div
  * query heads sharing a key / value head (kangaroo/adapter.py:69-78). */

@@ -128,11 +128,12 @@ struct KgMmArgs {
     long long sA, sB, sC; int batch;    // grid.z independent products z = zo * batch_inner + zi: element offsets zo * sX + zi * sX2
     int batch_inner; long long sA2, sB2, sC2;   // (B: (zi / b_inner_div) * sB2, query heads that share a key / value head); batch_inner 1: z = zo
     int b_inner_div;
-    int b_packed;                       // B in the packed 16 x 32 tile layout of the decode weights
+    int b_packed;                       // layout of B: 0 [N][K] rows, 1 the packed 16 x 32 tile layout of the decode weights, 2 [K][N] rows (K-major)
     int out_f32;                        // C is float instead of the 16-bit input type
     int causal;                         // 1: tiles of C entirely above the diagonal are skipped (not written); 2: A is lower
                                         //    triangular (row m has no entry beyond column m): K is walked up to the tile's last row;
-                                        // 3: A is upper triangular: K is walked from the tile's first row on
+                                        // 3: A is upper triangular: K is walked from the tile's first row on;
+                                        // 4: a K-major B whose row k ends at column k: K is walked from the tile's first column on
     float alpha;
     int tile;                           // 0: chosen by size; 1: 128 x 128 tiles; 2: 256 x 256 tiles (measurements)
 };

@@ -19,6 +19,11 @@
 // staging loads then walk a tile's 64 pieces in storage order, one full tile per wave-level load.
 // Rows / columns beyond M / N and k beyond K are read as zeros through range-checked buffer loads (the offset of a
 // piece that does not exist is forced out of range), so any M, N and any K that is a multiple of 8 work.
+// B can finally be given K-MAJOR, [K][N] with N contiguous (C = A . B, the form of the products that contract over the
+// rows of a stored matrix: dV^T = dO^T . P, dK^T = Q^T . dS): its tiles are staged as [k][n] rows and the fragments, which
+// want eight consecutive k of one n, come out of LDS through the transposing read ds_read_b64_tr_b16 (two per
+// fragment: a group of 16 lanes fetches a 4 x 16 block and each lane receives one column).  32-byte chunks of a row are
+// XORed with (k & 3) | ((k >> 3) & 1) << 2, which spreads the eight rows a 32-lane half reads over all banks.
 // grid.z walks `batch` independent products with element strides sA / sB / sC (attention heads).
 // Tiles are dealt to blocks so that the blocks resident on one XCD (block index mod 8) work on neighbouring tiles of a
 // band of 8 tile rows: they share the L2 copies of that band's A rows and of the B columns they walk.
@@ -29,8 +34,13 @@
 
 __device__ __forceinline__ unsigned mm_lds_off(int row, int chunk) { return (unsigned)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)); }
 
-template <int DT, int BM, int BN, int WM, int WN, bool PACKED_B, bool OUT_F32>
+typedef short mm_v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned mm_kmajor_key(int k) { return (unsigned)((k & 3) | (((k >> 3) & 1) << 2)); }
+
+// BMODE 0: B [N][K] row-major; 1: B in the packed tile layout; 2: B [K][N] (K-major)
+template <int DT, int BM, int BN, int WM, int WN, int BMODE, bool OUT_F32>
 __global__ void __launch_bounds__(WM * WN * 64) kg_mm_kernel(const KgMmArgs a) {
+    constexpr bool PACKED_B = (BMODE == 1), KMAJOR_B = (BMODE == 2);
     typedef KgT<DT> T;
     constexpr int MM_BM = BM, MM_BN = BN, NTHR = WM * WN * 64;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;            // MFMA tiles of a wave
@@ -56,14 +66,17 @@ __global__ void __launch_bounds__(WM * WN * 64) kg_mm_kernel(const KgMmArgs a) {
     const int zo = (int)blockIdx.z / a.batch_inner, zi = (int)blockIdx.z - zo * a.batch_inner;
     const unsigned short* Ab = (const unsigned short*)a.A + (size_t)zo * a.sA + (size_t)zi * a.sA2;
     const unsigned short* Bb = (const unsigned short*)a.B + (size_t)zo * a.sB + (size_t)(zi / a.b_inner_div) * a.sB2;
-    const size_t a_bytes = ((size_t)(a.M - 1) * a.lda + a.K) * 2, b_bytes = PACKED_B ? (size_t)((a.N + 15) / 16) * (a.K / 32) * 1024 : ((size_t)(a.N - 1) * a.ldb + a.K) * 2;
+    const size_t a_bytes = ((size_t)(a.M - 1) * a.lda + a.K) * 2;
+    const size_t b_bytes = PACKED_B ? (size_t)((a.N + 15) / 16) * (a.K / 32) * 1024 : (KMAJOR_B ? ((size_t)(a.K - 1) * a.ldb + a.N) * 2 : ((size_t)(a.N - 1) * a.ldb + a.K) * 2);
     const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)(a_bytes > 0x7fffffffu ? 0x7fffffffu : a_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)(b_bytes > 0x7fffffffu ? 0x7fffffffu : b_bytes), 0x00020000);
 
     // K range of this tile: a causal product with a lower-triangular A (P . V) or a lower-triangular C (dV = P^T . dO
     // handled by the caller through transposes) only needs k up to the tile's last row
     const int k_end = (a.causal == 2) ? min(a.K, m0 + MM_BM) : a.K;
-    const int kt0 = (a.causal == 3) ? m0 / MM_BK : 0;                  // an upper-triangular A: nothing before the tile's first row
+    // an upper-triangular A: nothing before the tile's first row; a K-major B whose row k ends at column k: nothing before
+    // the tile's first column
+    const int kt0 = (a.causal == 3) ? m0 / MM_BK : ((a.causal == 4) ? n0 / MM_BK : 0);
     const int KT = (k_end + MM_BK - 1) / MM_BK - kt0;
 
     // ---- staging: 4 pieces of 16 bytes per thread and operand ----
@@ -85,6 +98,10 @@ __global__ void __launch_bounds__(WM * WN * 64) kg_mm_kernel(const KgMmArgs a) {
             const int r = c & 15, g = (c >> 4) & 3, ktl = (c >> 6) & 1, rgl = c >> 7, row = rgl * 16 + r, ch = ktl * 4 + g;
             b_k[i] = 8 * ch; b_dst[i] = A_BYTES + mm_lds_off(row, ch);
             b_src[i] = (n0 + row < a.N) ? (unsigned)((((size_t)((n0 >> 4) + rgl) * (a.K >> 5) + ktl) * 512 + g * 128 + r * 8) * 2) : 0xFFFFFFFFu;
+        } else if (KMAJOR_B) {
+            const int k = c / (BN / 8), c16 = c % (BN / 8);              // row k of the step, 16-byte piece c16 of its BN columns
+            b_k[i] = k; b_dst[i] = A_BYTES + (unsigned)(k * (BN * 2) + ((((unsigned)c16 >> 1) ^ mm_kmajor_key(k)) << 5) + ((c16 & 1) << 4));
+            b_src[i] = (n0 + 8 * c16 < a.N) ? (unsigned)(((size_t)k * a.ldb + n0 + 8 * c16) * 2) : 0xFFFFFFFFu;
         } else {
             const int row = c >> 3, ch = c & 7;
             b_k[i] = 8 * ch; b_dst[i] = A_BYTES + mm_lds_off(row, ch);
@@ -102,7 +119,7 @@ __global__ void __launch_bounds__(WM * WN * 64) kg_mm_kernel(const KgMmArgs a) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
             const bool ok = (k0 + b_k[i] < k_end) && b_src[i] != 0xFFFFFFFFu;
-            const unsigned boff = PACKED_B ? b_src[i] + (unsigned)((k0 >> 5) * 1024) : b_src[i] + (unsigned)(k0 * 2);
+            const unsigned boff = PACKED_B ? b_src[i] + (unsigned)((k0 >> 5) * 1024) : (KMAJOR_B ? b_src[i] + (unsigned)((size_t)k0 * a.ldb * 2) : b_src[i] + (unsigned)(k0 * 2));
             sb[i] = __builtin_amdgcn_raw_buffer_load_b128(br, ok ? boff : 0xFFFFFFFFu, 0, 0);
         }
     };
@@ -130,7 +147,21 @@ __global__ void __launch_bounds__(WM * WN * 64) kg_mm_kernel(const KgMmArgs a) {
         for (int ks = 0; ks < MM_BK / 32; ++ks) {
             kg_u4 fa[TM], fb[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *(const kg_u4*)(lb + mm_lds_off(16 * j + fr, 4 * ks + fg));
+            for (int j = 0; j < TN; ++j) {
+                if (KMAJOR_B) {
+                    // rows k = 32 ks + 8 fg + (0..3 | 4..7), columns 16 j .. 16 j + 15 of this wave's part: lane 4q + p of a 16-lane
+                    // group addresses row q, columns 4p .. 4p + 3 and receives column (lane & 15) of the four rows
+                    const int q = fr >> 2, pp = fr & 3, kr = 32 * ks + 8 * fg + q;
+                    const int c32 = (wc * (BN / WN) + 16 * j) >> 4;
+                    const char* base = smem + (kt & 1) * STAGE + A_BYTES;
+                    const mm_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) mm_v4s*)(base + kr * (BN * 2) + ((((unsigned)c32) ^ mm_kmajor_key(kr)) << 5) + 8 * pp));
+                    const mm_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) mm_v4s*)(base + (kr + 4) * (BN * 2) + ((((unsigned)c32) ^ mm_kmajor_key(kr + 4)) << 5) + 8 * pp));
+                    fb[j].x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16); fb[j].y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+                    fb[j].z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16); fb[j].w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+                } else {
+                    fb[j] = *(const kg_u4*)(lb + mm_lds_off(16 * j + fr, 4 * ks + fg));
+                }
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = *(const kg_u4*)(la + mm_lds_off(16 * i + fr, 4 * ks + fg));
 #pragma unroll
@@ -170,43 +201,49 @@ __global__ void __launch_bounds__(WM * WN * 64) kg_mm_kernel(const KgMmArgs a) {
 }
 
 static int g_mm_ncu = 256;
-template <int DT, int BM, int BN, int WM, int WN, bool PACKED_B>
+template <int DT, int BM, int BN, int WM, int WN, int BMODE>
 static void mm_launch_tile(const KgMmArgs& a, hipStream_t st) {
     const size_t smem = 2 * (size_t)(BM + BN) * MM_BK * 2;
     const dim3 grid(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN), 1, a.batch), block(WM * WN * 64);
-    if (a.out_f32) hipLaunchKernelGGL((kg_mm_kernel<DT, BM, BN, WM, WN, PACKED_B, true>), grid, block, smem, st, a);
-    else hipLaunchKernelGGL((kg_mm_kernel<DT, BM, BN, WM, WN, PACKED_B, false>), grid, block, smem, st, a);
+    if (a.out_f32) hipLaunchKernelGGL((kg_mm_kernel<DT, BM, BN, WM, WN, BMODE, true>), grid, block, smem, st, a);
+    else hipLaunchKernelGGL((kg_mm_kernel<DT, BM, BN, WM, WN, BMODE, false>), grid, block, smem, st, a);
 }
-template <int DT, bool PACKED_B>
+template <int DT, int BMODE>
 static void mm_launch(const KgMmArgs& a, hipStream_t st) {
-    // the large tile once it fills the chip (and always when forced: a.tile == 2; a.tile == 1 forces the small one)
-    const long big_tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.batch;
-    const bool big = a.tile == 2 || (a.tile == 0 && big_tiles >= g_mm_ncu);
-    if (big) mm_launch_tile<DT, 256, 256, 2, 4, PACKED_B>(a, st);
-    else mm_launch_tile<DT, 128, 128, 2, 2, PACKED_B>(a, st);
+    // Rounds of blocks x time of a round.  A CU holds one 256 x 256 block, which runs ~1.4 times as fast per flop as one
+    // of the two 128 x 128 blocks it holds instead (they share the CU, and a small tile moves twice the bytes per flop
+    // through the L2-to-CU path): a round of large tiles costs 65536 / 1.4, a round of small ones 16384 / 0.5.  Measured:
+    // 8192 x 4096 x 4096 is 296 us against 410 us (model 0.71), 640 x 22016 x 4096 232 against 167 us.
+    const double t_big = (double)(((long)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.batch + g_mm_ncu - 1) / g_mm_ncu) * (65536.0 / 1.4);
+    const double t_small = (double)(((long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch + 2 * g_mm_ncu - 1) / (2 * g_mm_ncu)) * (16384.0 / 0.5);
+    const bool big = a.tile == 2 || (a.tile == 0 && t_big < t_small);
+    if (big) mm_launch_tile<DT, 256, 256, 2, 4, BMODE>(a, st);
+    else mm_launch_tile<DT, 128, 128, 2, 2, BMODE>(a, st);
 }
 
 int kg_launch_mm(const KgMmArgs& a, int dtype, hipStream_t st) {
     if (!a.A || !a.B || !a.C || a.M < 1 || a.N < 1 || a.K < 8 || (a.K & 7) || a.batch < 1 || a.batch > 65535) return -1;
-    if ((a.lda & 7) || (!a.b_packed && (a.ldb & 7)) || (a.sA & 7) || (a.sB & 7)) return -1;      // 16-byte pieces
-    if (a.b_packed && ((a.K & 31) || a.batch != 1)) return -1;
-    if (a.causal < 0 || a.causal > 3) return -1;
+    if ((a.lda & 7) || (a.b_packed != 1 && (a.ldb & 7)) || (a.sA & 7) || (a.sB & 7)) return -1;      // 16-byte pieces
+    if (a.b_packed < 0 || a.b_packed > 2) return -1;
+    if (a.b_packed == 1 && ((a.K & 31) || a.batch != 1)) return -1;
+    if (a.b_packed == 2 && (a.N & 7)) return -1;
+    if (a.causal < 0 || a.causal > 4 || (a.causal == 4 && a.b_packed != 2)) return -1;
     if (a.batch_inner < 1 || a.batch % a.batch_inner || a.b_inner_div < 1 || (a.sA2 & 7) || (a.sB2 & 7)) return -1;
     if (a.tile < 0 || a.tile > 2) return -1;
-    if (dtype == KG_F16) { if (a.b_packed) mm_launch<KG_F16, true>(a, st); else mm_launch<KG_F16, false>(a, st); }
-    else { if (a.b_packed) mm_launch<KG_BF16, true>(a, st); else mm_launch<KG_BF16, false>(a, st); }
+    if (dtype == KG_F16) { if (a.b_packed == 1) mm_launch<KG_F16, 1>(a, st); else if (a.b_packed == 2) mm_launch<KG_F16, 2>(a, st); else mm_launch<KG_F16, 0>(a, st); }
+    else { if (a.b_packed == 1) mm_launch<KG_BF16, 1>(a, st); else if (a.b_packed == 2) mm_launch<KG_BF16, 2>(a, st); else mm_launch<KG_BF16, 0>(a, st); }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-template <int DT, bool P, bool F> static void mm_attr() {
+template <int DT, int P, bool F> static void mm_attr() {
     (void)hipFuncSetAttribute((const void*)kg_mm_kernel<DT, 128, 128, 2, 2, P, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * MM_BK * 2);
     (void)hipFuncSetAttribute((const void*)kg_mm_kernel<DT, 256, 256, 2, 4, P, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * MM_BK * 2);
 }
 void kg_mm_init() {
     int dev = 0, ncu = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) g_mm_ncu = ncu;
-    mm_attr<KG_F16, false, false>(); mm_attr<KG_F16, false, true>(); mm_attr<KG_F16, true, false>(); mm_attr<KG_F16, true, true>();
-    mm_attr<KG_BF16, false, false>(); mm_attr<KG_BF16, false, true>(); mm_attr<KG_BF16, true, false>(); mm_attr<KG_BF16, true, true>();
+    mm_attr<KG_F16, 0, false>(); mm_attr<KG_F16, 0, true>(); mm_attr<KG_F16, 1, false>(); mm_attr<KG_F16, 1, true>(); mm_attr<KG_F16, 2, false>(); mm_attr<KG_F16, 2, true>();
+    mm_attr<KG_BF16, 0, false>(); mm_attr<KG_BF16, 0, true>(); mm_attr<KG_BF16, 1, false>(); mm_attr<KG_BF16, 1, true>(); mm_attr<KG_BF16, 2, false>(); mm_attr<KG_BF16, 2, true>();
     (void)hipGetLastError();
 }
 

@@ -12,8 +12,9 @@ entropy, train.py:265-278).  Per step and rank:
 
 Every matrix product is kg_matmul_nt (csrc/mm.hip: C = A . B^T on the matrix cores, 256 x 256 tiles), the heads of
 [B, S, H, hd] tensors addressed in place (kg_matmul_nt_heads), causal products skipping the empty half; a product
-whose contraction index is not contiguous in one operand first transposes that operand (kg_transpose16: the weights
-once per step, the head once for good, activations for the weight gradients).  Everything between the products is a
+whose contraction index is not contiguous in an operand takes that operand K-major where it is one of the [S, S]
+matrices (dV^T = dO^T . P, dK^T = Q^T . dS) and transposes it first otherwise (kg_transpose16: the weights once per
+step, the head once for good, activations for the weight gradients).  Everything between the products is a
 hand-written kernel of csrc/train.hip.  With 288 GB of HBM the step materialises the attention probabilities
 [B, H, S, S] and both logit matrices [B*S, V] in 16 bit instead of recomputing them (4 x 2048 tokens at the 7B shape:
 1 GiB + 2 x 0.5 GiB).  torch only allocates.
@@ -286,26 +287,25 @@ class AdapterTrainer:
         # dprobs[b, h] = dctx[b, :, h] . v[b, :, h // rep]^T (causal half), then dscores in place
         dprobs = torch.empty((B, H, S, S), dtype=dt, device=dev)
         heads(dctx, qd, S * qd, hd, v, kvd, S * kvd, hd, dprobs, S, H * S * S, S * S, S, S, hd, 1)
-        # dv[b, :, h] = probs[b, h]^T . dctx[b, :, h]: rows = keys, contraction over the queries at or after the key
-        probs_t = self._transpose(probs.view(B * H, S, S), B * H)
+        # dv[b, :, h]^T = dctx[b, :, h]^T . probs[b, h]: the contraction runs over the queries (at or after each key), i.e. over
+        # the ROWS of the stored probabilities, which go in as they lie (K-major B); the result comes out transposed
         dctx_t = self._transpose(dctx.view(B, S, qd), B)                             # [B, H hd, S]
-        dvh = torch.empty((B, S, H, hd), dtype=dt, device=dev)
-        _lib.check(self.lib.kg_matmul_nt_heads(self.dt, self._p(probs_t), self._p(dctx_t), self._p(dvh), S, hd, S, S, S, qd, B * H, H * S * S, qd * S, S * qd,
-                                               H, S * S, hd * S, hd, 1, 0, 0, 3, 1.0, self._st()), "kg_matmul_nt_heads")
-        del probs_t
+        dv_t = torch.empty((B, qd, S), dtype=dt, device=dev)
+        _lib.check(self.lib.kg_matmul_nt_heads(self.dt, self._p(dctx_t), self._p(probs), self._p(dv_t), hd, S, S, S, S, S, B * H, qd * S, H * S * S, qd * S,
+                                               H, hd * S, S * S, hd * S, 1, 2, 0, 4, 1.0, self._st()), "kg_matmul_nt_heads")
+        dvh = self._transpose(dv_t, B).view(B, S, H, hd)
         _lib.check(self.lib.kg_train_softmax_bwd(self.dt, self._p(probs), self._p(dprobs), B, H, S, scale, self._st()), "kg_train_softmax_bwd")
         del probs
         # dq[b, :, h] = dscores[b, h] . k[b, :, h // rep] (keys contracted: K transposed); dk[b, :, h] = dscores[b, h]^T . q[b, :, h]
         kt = self._transpose(k.view(B, S, kvd), B)                                   # [B, Hkv hd, S]
         dq = torch.empty((R, qd), dtype=dt, device=dev)
         heads(dprobs, S, H * S * S, S * S, kt, S, kvd * S, hd * S, dq, qd, S * qd, hd, S, hd, S, 2)
-        ds_t = self._transpose(dprobs.view(B * H, S, S), B * H)
-        del dprobs
         q_t = self._transpose(q.view(B, S, qd), B)                                   # [B, H hd, S]
-        dkh = torch.empty((B, S, H, hd), dtype=dt, device=dev)
-        _lib.check(self.lib.kg_matmul_nt_heads(self.dt, self._p(ds_t), self._p(q_t), self._p(dkh), S, hd, S, S, S, qd, B * H, H * S * S, qd * S, S * qd,
-                                               H, S * S, hd * S, hd, 1, 0, 0, 3, 1.0, self._st()), "kg_matmul_nt_heads")
-        del ds_t
+        dk_t = torch.empty((B, qd, S), dtype=dt, device=dev)
+        _lib.check(self.lib.kg_matmul_nt_heads(self.dt, self._p(q_t), self._p(dprobs), self._p(dk_t), hd, S, S, S, S, S, B * H, qd * S, H * S * S, qd * S,
+                                               H, hd * S, S * S, hd * S, 1, 2, 0, 4, 1.0, self._st()), "kg_matmul_nt_heads")
+        del dprobs
+        dkh = self._transpose(dk_t, B).view(B, S, H, hd)
         if rep > 1:                                                                  # query heads that shared a key / value head
             dk = dkh.view(B, S, Hkv, rep, hd).sum(dim=3).reshape(R, kvd).contiguous()
             dv = dvh.view(B, S, Hkv, rep, hd).sum(dim=3).reshape(R, kvd).contiguous()

@@ -58,6 +58,18 @@ for dt in (torch.float16, torch.bfloat16):
     pad = lambda t: torch.nn.functional.pad(t, (0, 4))         # K = 304: a multiple of 8
     O = mm(pad(P), pad(Vt), out_f32=True, causal=2)
     assert float((O - P.float() @ Vt.float().transpose(1, 2)).abs().max()) < 1e-3 * 300 ** 0.5
+    # K-major B: dV^T[hd, S_k] = dO^T[hd, S_q] . P[S_q, S_k], only queries at or after each key (causal 4)
+    Sq = 296
+    Pm = (torch.rand(6, Sq, Sq, device=dev, generator=g) * torch.ones(Sq, Sq, device=dev).tril()).to(dt); dOt = torch.randn(6, 128, Sq, device=dev, generator=g).to(dt)
+    for caus in (0, 4):
+        out = torch.empty(6, 128, Sq, dtype=torch.float32, device=dev)
+        _lib.check(lib.kg_matmul_nt(dtc := (_lib.DT_F16 if dt == torch.float16 else _lib.DT_BF16), dOt.data_ptr(), Pm.data_ptr(), out.data_ptr(), 128, Sq, Sq, Sq, Sq, Sq,
+                                    6, 128 * Sq, Sq * Sq, 128 * Sq, 2, 1, caus, 1.0, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "kg_matmul_nt (K-major B)")
+        assert float((out - dOt.float() @ Pm.float()).abs().max()) < 1e-3 * Sq ** 0.5, caus
+    Bk = torch.randn(520, 136, device=dev, generator=g).to(dt); Ak = torch.randn(77, 520, device=dev, generator=g).to(dt)
+    out = torch.empty(77, 136, dtype=torch.float32, device=dev)
+    _lib.check(lib.kg_matmul_nt(dtc, Ak.data_ptr(), Bk.data_ptr(), out.data_ptr(), 77, 136, 520, 520, 136, 136, 1, 0, 0, 0, 2, 1, 0, 1.0, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "kg_matmul_nt (K-major B)")
+    assert float((out - Ak.float() @ Bk.float()).abs().max()) < 1e-3 * 520 ** 0.5
     T_ = torch.randn(3, 70, 200, device=dev, generator=g).to(dt)
     out = torch.empty(3, 200, 70, dtype=dt, device=dev)
     _lib.check(lib.kg_transpose16(T_.data_ptr(), out.data_ptr(), 70, 200, 200, 70, 3, 70 * 200, 70 * 200, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "kg_transpose16")
