@@ -141,6 +141,10 @@ __global__ void __launch_bounds__(WM * WN * 64) kg_mm_kernel(const KgMmArgs a) {
     if (KT > 1) stage_load(1);
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
+        // The registers hold step kt + 1, requested a whole step ago: park it in the other LDS buffer (last read in step
+        // kt - 1, which every wave has left) and request step kt + 2 before this step's MFMAs, which hide both.
+        if (kt + 1 < KT) stage_store((kt + 1) & 1);
+        if (kt + 2 < KT) stage_load(kt + 2);
         const char* la = smem + (kt & 1) * STAGE + wr * (BM / WM) * 128;
         const char* lb = smem + (kt & 1) * STAGE + A_BYTES + wc * (BN / WN) * 128;
 #pragma unroll
@@ -169,32 +173,46 @@ __global__ void __launch_bounds__(WM * WN * 64) kg_mm_kernel(const KgMmArgs a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma(fb[j], fa[i], acc[i][j]);       // D[n = 4 fg + e][m = fr]
         }
-        if (kt + 1 < KT) stage_store((kt + 1) & 1);       // the other buffer: last read in step kt - 1, which every wave has left
-        if (kt + 2 < KT) stage_load(kt + 2);
         __syncthreads();
     }
 
-    // ---- epilogue ----
+    // ---- epilogue: the wave's part goes through its own LDS region and leaves in whole rows ----
+    // (a lane's accumulators are 4 columns of 16 different rows: stored directly, every wave-level store would touch 16 rows
+    //  with 32 bytes each)
     const size_t cb = (size_t)zo * a.sC + (size_t)zi * a.sC2;
+    constexpr int WROWS = BM / WM, WCOLS = BN / WN;              // the wave's part of the tile
+    constexpr int ESZ = OUT_F32 ? 4 : 2;
+    constexpr int ROWB = WCOLS * ESZ + 16;                       // padded row of the staging image (keeps 16-byte alignment, staggers banks)
+    static_assert((size_t)WM * WN * 16 * ROWB <= 2 * (size_t)(BM + BN) * MM_BK * 2, "staging image fits the pipeline's LDS");
+    char* stg = smem + wave * 16 * ROWB;                         // 16 rows at a time
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wr * (BM / WM) + 16 * i + fr;
-        if (m >= a.M) continue;
+        // all waves are past the last step's barrier; a wave only touches its own region from here on
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wc * (BN / WN) + 16 * j + 4 * fg;
-            if (n >= a.N) continue;
             kg_f4 v = acc[i][j];
             if (a.alpha != 1.0f) v = v * a.alpha;
-            if (OUT_F32) {
-                float* dst = (float*)a.C + cb + (size_t)m * a.ldc + n;
-                if (n + 3 < a.N && ((a.ldc | n) & 3) == 0) *(kg_f4*)dst = v;
-                else for (int e = 0; e < 4 && n + e < a.N; ++e) dst[e] = v[e];
-            } else {
-                unsigned short* dst = (unsigned short*)a.C + cb + (size_t)m * a.ldc + n;
-                const unsigned short h0 = T::from_f(v[0]), h1 = T::from_f(v[1]), h2 = T::from_f(v[2]), h3 = T::from_f(v[3]);
-                if (n + 3 < a.N && ((a.ldc | n) & 3) == 0) *(unsigned long long*)dst = (unsigned long long)h0 | ((unsigned long long)h1 << 16) | ((unsigned long long)h2 << 32) | ((unsigned long long)h3 << 48);
-                else { const unsigned short h[4] = {h0, h1, h2, h3}; for (int e = 0; e < 4 && n + e < a.N; ++e) dst[e] = h[e]; }
+            char* dst = stg + fr * ROWB + (16 * j + 4 * fg) * ESZ;
+            if (OUT_F32) *(kg_f4*)dst = v;
+            else *(unsigned long long*)dst = (unsigned long long)T::from_f(v[0]) | ((unsigned long long)T::from_f(v[1]) << 16) | ((unsigned long long)T::from_f(v[2]) << 32) | ((unsigned long long)T::from_f(v[3]) << 48);
+        }
+        // 16 rows x WCOLS elements: 16-byte pieces, consecutive lanes along a row
+        constexpr int PPR = WCOLS * ESZ / 16, NP = 16 * PPR;     // pieces per row, pieces of the 16 rows
+#pragma unroll
+        for (int c = lane; c < NP; c += 64) {
+            const int r = c / PPR, pc = c - r * PPR;
+            const int m = m0 + wr * WROWS + 16 * i + r, n = n0 + wc * WCOLS + pc * (16 / ESZ);
+            const kg_u4 v = *(const kg_u4*)(stg + r * ROWB + pc * 16);
+            if (m < a.M && n < a.N) {
+                char* out = (char*)a.C + (cb + (size_t)m * a.ldc + n) * ESZ;
+                if (n + 16 / ESZ <= a.N && (((a.ldc | n) * ESZ) & 15) == 0 && ((cb * ESZ) & 15) == 0) *(kg_u4*)out = v;
+                else {
+                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                    for (int e = 0; e < 16 / ESZ && n + e < a.N; ++e) {
+                        if (OUT_F32) ((float*)out)[e] = __builtin_bit_cast(float, w[e]);
+                        else ((unsigned short*)out)[e] = (unsigned short)(w[e >> 1] >> (16 * (e & 1)));
+                    }
+                }
             }
         }
     }
