@@ -392,6 +392,75 @@ __global__ void __launch_bounds__(NT * ATT_NW * 64) kg_attn_mfma_kernel(const Kg
     split_combine<DT, false>(a, h, HD, row0, M, n_act, tid, NT * ATT_NW * 64, lds_all[0].cl, last);
 }
 
+// ---------------------------------------------------------------------------------
+// Causal attention of a whole prompt (rows at positions pos0 .. pos0 + rows - 1 over cache slots [0, pos0 + rows)), for the
+// prompt pass that runs layer by layer: one WAVE owns 16 query rows and walks all their keys in 32-key tiles with the tile
+// code of the decode kernel (scores and P.V on v_mfma_f32_16x16x32, online softmax, next tile requested before the current
+// one is used), so there are no key splits, no partials and no merge; a block is four such waves (64 rows) of one head,
+// whose K/V requests meet in L2.  Row blocks are dealt to waves from both ends of the prompt so that a block's work is
+// even under the causal bound.  V is read from the transposed cache layout [Hkv][hd][t_max].
+template <int DT, int HD>
+__global__ void __launch_bounds__(256) kg_attn_rows_kernel(const unsigned short* q, const unsigned short* k_cache, const unsigned short* v_cache, unsigned short* out,
+                                                           int rows, int pos0, int H, int Hkv, int t_max) {
+    typedef KgT<DT> T;
+    constexpr int KS = HD / 32, DB = HD / 16;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, kvh = h / (H / Hkv);
+    const int nrb = (rows + 15) >> 4;
+    // wave slot s = 4 * blockIdx.x + wave takes row block s / 2 from the front (s even) or from the back (s odd)
+    const int slot = 4 * blockIdx.x + wave;
+    if (slot >= nrb) return;
+    const int rb = (slot & 1) ? (nrb - 1 - (slot >> 1)) : (slot >> 1);
+    const int row0 = 16 * rb, M = min(16, rows - row0);
+    const int len = pos0 + row0 + M;
+    const int lim = (c < M) ? (pos0 + row0 + c) : -1;
+    const __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, (int)((size_t)rows * H * HD * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc((void*)(k_cache + (size_t)kvh * t_max * HD), 0, (int)((size_t)t_max * HD * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void*)(v_cache + (size_t)kvh * HD * t_max), 0, (int)((size_t)t_max * HD * 2), 0x00020000);
+    kg_u4 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)       // rows beyond the prompt are out of range: zeros
+        qf[s] = __builtin_amdgcn_raw_buffer_load_b128(qr, (unsigned)((((size_t)(row0 + c) * H + h) * HD + 32 * s + 8 * g) * 2), 0, 0);
+    const float inv_scale = sqrtf((float)HD);
+    float mrun = -INFINITY, lsum = 0.f;
+    kg_f4 O[DB];
+#pragma unroll
+    for (int b = 0; b < DB; ++b) O[b] = kg_f4{0.f, 0.f, 0.f, 0.f};
+    KgAttnTile<HD> nxt;
+    attn_tile_load<HD, 0>(nxt, kr, vr, t_max, 0, lane);
+    for (int tb = 0; tb < len; tb += 32) {
+        const KgAttnTile<HD> cur = nxt;
+        if (tb + 32 < len) attn_tile_load<HD, 0>(nxt, kr, vr, t_max, tb + 32, lane);
+        attn_tile_compute<DT, HD>(cur, qf, tb, len, lim, inv_scale, lane, mrun, lsum, O);
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    // accumulator rows are query rows 4g .. 4g + 3, their sums sit in the lanes that own those columns
+    float linv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) linv[i] = 1.0f / __shfl(lsum, (lane & 48) | (4 * g + i), 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = row0 + 4 * g + i;
+        if (4 * g + i < M) {
+            unsigned short* dst = out + ((size_t)m * H + h) * HD + c;
+#pragma unroll
+            for (int b = 0; b < DB; ++b) dst[16 * b] = T::from_f(O[b][i] * linv[i]);
+        }
+    }
+}
+
+int kg_launch_attn_rows(const void* q, const void* k_cache, const void* v_cache, void* out, int rows, int pos0, int H, int Hkv, int hd, int t_max, int dtype, hipStream_t st) {
+    if (!q || !k_cache || !v_cache || !out || rows < 1 || pos0 < 0 || pos0 + rows > t_max || H % Hkv || (t_max & 31)) return -1;
+    const dim3 grid(((rows + 15) / 16 + 3) / 4, H);
+#define KG_AR(D, HD_) hipLaunchKernelGGL((kg_attn_rows_kernel<D, HD_>), grid, dim3(256), 0, st, (const unsigned short*)q, (const unsigned short*)k_cache, (const unsigned short*)v_cache, (unsigned short*)out, rows, pos0, H, Hkv, t_max)
+    if (dtype == KG_F16) { switch (hd) { case 32: KG_AR(KG_F16, 32); break; case 64: KG_AR(KG_F16, 64); break; case 128: KG_AR(KG_F16, 128); break; default: return -1; } }
+    else { switch (hd) { case 32: KG_AR(KG_BF16, 32); break; case 64: KG_AR(KG_BF16, 64); break; case 128: KG_AR(KG_BF16, 128); break; default: return -1; } }
+#undef KG_AR
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 template <int DT, int LPR>
 static void launch_lpr(const KgAttnArgs& a, hipStream_t st) {
     if (a.max_rows == 1) {

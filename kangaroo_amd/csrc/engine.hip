@@ -72,6 +72,10 @@ struct kg_session {
     char* rot; size_t rot_layer;       // per-layer activation buffers of the persistent passes
     char *pf_h, *pf_xn, *pf_xq, *pf_ao, *pf_act;   // activations of a prefill pass (KG_GEMM_ROWS rows)
     float* pf_part;                    // K-range partial sums of the d-row prefill projections [4][KG_GEMM_ROWS][d]
+    // prompt pass that runs layer by layer over the whole prompt (t_max rows each): hidden rows, normalised rows, stored
+    // q/k/v rows, q in head order, attention output, MLP activations
+    char *pm_h, *pm_xn, *pm_qkv, *pm_q, *pm_ao, *pm_act;
+    int rows_prefill_min;              // prompts of at least this many tokens take that pass (0: never)
     int gemm_prefill;                  // 1: prompts go through the 128-row GEMM passes
     int vanilla_gemv;                  // 1: plain decoding runs every layer and the head through the 1-row GEMV kernels
     int bench_layers;                  // kg_bench_op cycles through this many layers' weights (1: cache-warm)
@@ -151,7 +155,15 @@ static void carve(kg_session* s, Carver& c, const kg_shape* sh, int t_max) {
     char* pf_ao = c.take<char>(PR * qd * e);
     char* pf_act = c.take<char>(PR * F * e);
     float* pf_part = c.take<float>(4 * PR * d);
+    const size_t TR = (size_t)t_max, kvd2 = 2 * (size_t)sh->num_kv_heads * sh->head_dim;
+    char* pm_h = c.take<char>(TR * d * e);
+    char* pm_xn = c.take<char>(TR * d * e);
+    char* pm_qkv = c.take<char>(TR * (qd + kvd2) * e);
+    char* pm_q = c.take<char>(TR * qd * e);
+    char* pm_ao = c.take<char>(TR * qd * e);
+    char* pm_act = c.take<char>(TR * F * e);
     if (s) {
+        s->pm_h = pm_h; s->pm_xn = pm_xn; s->pm_qkv = pm_qkv; s->pm_q = pm_q; s->pm_ao = pm_ao; s->pm_act = pm_act;
         s->prog_dev[0] = prog0; s->prog_dev[1] = prog1; s->prog_dev[2] = prog2; s->prog_cap = prog_cap; s->bar = bar; s->rot = rot; s->rot_layer = rot_layer;
         s->pf_h = pf_h; s->pf_xn = pf_xn; s->pf_xq = pf_xq; s->pf_ao = pf_ao; s->pf_act = pf_act; s->pf_part = pf_part;
         s->state = state; s->tokens = tokens;
@@ -207,6 +219,9 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     s->accept_top_p = 0.f; s->temperature = 1.f;
     s->accept_typical = 0; s->typical_epsilon = 0.3f; s->typical_delta = 0.09f;
     s->gemm_prefill = s->v_transposed;           // the GEMM passes need the MFMA attention kernel
+    // From 192 prompt tokens on the prompt goes through the layers one whole-prompt pass at a time (measured at the 7B
+    // shape: 640 tokens 25.5 ms in 128-row passes); shorter prompts fill too few tiles of the large matrix products.
+    s->rows_prefill_min = (s->v_transposed && shape->hidden_size % 8 == 0 && shape->intermediate_size % 8 == 0) ? 192 : 0;
     s->bench_layers = s->sh.num_layers;
     s->vanilla_gemv = 0;
     s->attn_teams = 1;
@@ -258,6 +273,7 @@ extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
     bool done = false;
     if (k == "attn_nsplit") { if (value > 32) return fail(-1, "nsplit <= 32"); s->attn_nsplit = value; done = true; }
     if (k == "gemm_prefill") { s->gemm_prefill = (value >= 2 && s->v_transposed) ? 1 : 0; done = true; }   // 1: off, 2: on
+    if (k == "rows_prefill_min") { s->rows_prefill_min = (value >= 2 && s->v_transposed) ? value : 0; done = true; }   // 1: off
     if (k == "vanilla_gemv") { s->vanilla_gemv = value >= 2 ? 1 : 0; done = true; }   // 1: off, 2: on
     if (k == "bench_layers") { s->bench_layers = value < s->sh.num_layers ? value : s->sh.num_layers; done = true; }
     if (k == "accept_top_k") { if (value > s->sh.vocab_size) return fail(-1, "accept_top_k <= vocab_size"); s->accept_top_k = value; done = true; }
@@ -331,6 +347,7 @@ extern "C" int kg_session_get(kg_session* s, const char* key) {
     if (k == "accept_top_k") return s->accept_top_k;
     if (k == "accept_typical") return s->accept_typical;
     if (k == "gemm_prefill") return s->gemm_prefill;
+    if (k == "rows_prefill_min") return s->rows_prefill_min;
     if (k == "vanilla_gemv") return s->vanilla_gemv;
     if (k == "persist") return s->persist;
     if (k == "prefill_rows") return s->prefill_rows;
@@ -1021,9 +1038,55 @@ static int run_layer_gemm_tp(kg_session* s, int l, const KgDyn* dyn, const void*
 // Prefill: all layers over the prompt in passes of C rows (128-row GEMM passes, or prefill_rows
 // rows through the decode kernels); keeps the input of the exit layer for the adapter's cache
 // (inference_kangaroo.py:30-38).
+// One decoder layer over `rows` prompt rows at positions 0 .., every projection ONE matrix product over all rows
+// (csrc/mm.hip reading the packed weights), the row kernels of prefill.hip between them, attention in 128-row launches.
+// lw.wgu == NULL: attention half only (the adapter layer).  h_in / h_out may alias.
+static int run_layer_rows(kg_session* s, const kg_layer_weights& lw, void* kc, void* vc, int rows, const void* h_in, void* h_out, hipStream_t st) {
+    const kg_shape& sh = s->sh;
+    const int d = sh.hidden_size, F = sh.intermediate_size, dt = sh.dtype, nqkv = s->q_dim + 2 * s->kv_dim;
+    auto mm = [&](const void* A, int K, const void* Wp, int N, void* C, int ldc, int epi, const void* resid) -> int {
+        KgMmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.A = A; a.B = Wp; a.C = C; a.M = rows; a.N = N; a.K = K; a.lda = K; a.ldc = ldc; a.batch = 1; a.batch_inner = 1; a.b_inner_div = 1;
+        a.b_packed = 1; a.alpha = 1.0f; a.epi = epi; a.resid = resid; a.ldr = d;
+        return kg_launch_mm(a, dt, st);
+    };
+    KG_TRY(kg_launch_rows_rmsnorm(h_in, d, lw.norm1, sh.rms_eps, d, s->pm_xn, d, rows, dt, st));
+    KG_TRY(mm(s->pm_xn, d, lw.wqkv, nqkv, s->pm_qkv, nqkv, MM_EPI_STORE, nullptr));
+    KG_TRY(kg_launch_rows_rope_kv(s->pm_qkv, rows, 0, sh.head_dim, s->q_dim, s->kv_dim, s->w.rope_cos, s->w.rope_sin, s->pm_q, kc, vc, s->buf.t_max, s->v_transposed, dt, st));
+    KG_TRY(kg_launch_attn_rows(s->pm_q, kc, vc, s->pm_ao, rows, 0, sh.num_heads, sh.num_kv_heads, sh.head_dim, s->buf.t_max, dt, st));
+    KG_TRY(mm(s->pm_ao, s->q_dim, lw.wo, d, h_out, d, MM_EPI_RESID, h_in));
+    if (lw.wgu == nullptr) return 0;
+    KG_TRY(kg_launch_rows_rmsnorm(h_out, d, lw.norm2, sh.rms_eps, d, s->pm_xn, d, rows, dt, st));
+    KG_TRY(mm(s->pm_xn, d, lw.wgu, 2 * F, s->pm_act, F, MM_EPI_SILU_MUL, nullptr));
+    return mm(s->pm_act, F, lw.wdown, d, h_out, d, MM_EPI_RESID, h_out);
+}
+
+// The prompt pass layer by layer (weights streamed once per layer whatever the prompt length); see prefill().
+static int prefill_rows_pass(kg_session* s, int T0, bool with_adapter, hipStream_t st) {
+    const kg_shape& sh = s->sh;
+    const int d = sh.hidden_size, L = sh.exit_layer, N = sh.num_layers;
+    const size_t rowb = (size_t)d * s->elt;
+    KG_TRY(kg_launch_rows_embed(s->tokens, 0, T0, s->w.embed, d, s->pm_h, st));
+    const void* cur = s->pm_h;
+    for (int l = 0; l < N; ++l) {
+        void* dst = (l == L - 1) ? (void*)s->hs_early : (void*)s->pm_h;          // the exit layer's input rows are kept for the adapter
+        KG_TRY(run_layer_rows(s, s->layers[l], layer_k(s, l), layer_v(s, l), T0, cur, dst, st));
+        cur = dst;
+    }
+    // first new token from the last row's logits (:33-34)
+    KG_TRY(kg_launch_set_dyn(s->dyn_call, 1, 1, T0 - 1, st));
+    int nb = 0;
+    KG_TRY(run_head(s, s->dyn_call, 1, (const char*)cur + (size_t)(T0 - 1) * rowb, 0, s->w.final_norm, nullptr, &nb, st));
+    KG_TRY(kg_launch_vanilla_end(loop_bufs(s), s->head_part, nb, st));
+    if (with_adapter) KG_TRY(run_layer_rows(s, s->w.adapter, s->buf.ak_cache, s->buf.av_cache, T0, s->hs_early, s->pm_h, st));
+    return 0;
+}
+
 static int prefill(kg_session* s, int T0, bool with_adapter, hipStream_t st) {
     const kg_shape& sh = s->sh;
     const int d = sh.hidden_size, L = sh.exit_layer, N = sh.num_layers;
+    if (s->rows_prefill_min > 0 && T0 >= s->rows_prefill_min && s->tp.size == 0 && L < N) return prefill_rows_pass(s, T0, with_adapter, st);
     const bool gemm = s->gemm_prefill && T0 > s->prefill_rows;
     const int C = gemm ? KG_GEMM_ROWS : s->prefill_rows;
     char* hb = gemm ? s->pf_h : s->h;

@@ -68,6 +68,8 @@ struct KgAttnArgs {
     int pf_min_chunks;          // fetch only when at least this many chunks hold keys: a shorter pass ends before the fetch does
 };
 int kg_launch_attn(const KgAttnArgs& a, int dtype, hipStream_t st);
+// causal attention of `rows` prompt rows at positions pos0 .. in one launch (head_dim 32 / 64 / 128, V cached transposed)
+int kg_launch_attn_rows(const void* q, const void* k_cache, const void* v_cache, void* out, int rows, int pos0, int H, int Hkv, int hd, int t_max, int dtype, hipStream_t st);
 void kg_attn_init();
 
 // persistent pass kernel: a list of phases walked by resident blocks (see persist.hip)
@@ -136,7 +138,17 @@ struct KgMmArgs {
                                         // 4: a K-major B whose row k ends at column k: K is walked from the tile's first column on
     float alpha;
     int tile;                           // 0: chosen by size; 1: 128 x 128 tiles; 2: 256 x 256 tiles (measurements)
+    // 16-bit output only.  epi 1: C = round16(resid + round16(A.B^T)) (the residual add of a decoder layer, resid rows ldr
+    // elements apart); epi 2: columns (2i, 2i+1) hold (gate_i, up_i) and C[m][i] = silu(gate) * up with the reference's
+    // roundings (N / 2 output columns, ldc counts those)
+    int epi; const void* resid; long long ldr;
 };
+enum { MM_EPI_STORE = 0, MM_EPI_RESID = 1, MM_EPI_SILU_MUL = 2 };
+// rows of the prompt pass that runs layer by layer over the whole prompt (prefill.hip)
+int kg_launch_rows_rmsnorm(const void* x, int ld, const void* w, float eps, int K, void* out, int ld_out, int rows, int dtype, hipStream_t st);
+int kg_launch_rows_rope_kv(const void* qkv, int rows, int pos0, int head_dim, int q_dim, int kv_dim, const float* rope_cos, const float* rope_sin,
+                           void* q_out, void* k_cache, void* v_cache, int t_max, int v_transposed, int dtype, hipStream_t st);
+int kg_launch_rows_embed(const int* tokens, int pos0, int rows, const void* embed, int d, void* out, hipStream_t st);
 int kg_launch_mm(const KgMmArgs& a, int dtype, hipStream_t st);
 void kg_mm_init();
 int kg_launch_transpose16(const void* in, void* out, int R, int Cn, long long ld_in, long long ld_out, int batch, long long s_in, long long s_out, hipStream_t st);

@@ -35,6 +35,11 @@
 __device__ __forceinline__ unsigned mm_lds_off(int row, int chunk) { return (unsigned)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)); }
 
 typedef short mm_v4s __attribute__((ext_vector_type(4)));
+// silu(g) * u with a 16-bit store after every op, as the reference computes it on stored tensors (kangaroo/adapter.py:242)
+template <int DT> __device__ __forceinline__ float mm_silu_mul(float g, float u) {
+    const float s = kg_round<DT>(g / (1.0f + expf(-g)));
+    return kg_round<DT>(s * u);
+}
 __device__ __forceinline__ unsigned mm_kmajor_key(int k) { return (unsigned)((k & 3) | (((k >> 3) & 1) << 2)); }
 
 // BMODE 0: B [N][K] row-major; 1: B in the packed tile layout; 2: B [K][N] (K-major)
@@ -203,6 +208,34 @@ __global__ void __launch_bounds__(WM * WN * 64) kg_mm_kernel(const KgMmArgs a) {
             const int r = c / PPR, pc = c - r * PPR;
             const int m = m0 + wr * WROWS + 16 * i + r, n = n0 + wc * WCOLS + pc * (16 / ESZ);
             const kg_u4 v = *(const kg_u4*)(stg + r * ROWB + pc * 16);
+            if (!OUT_F32 && a.epi == MM_EPI_SILU_MUL) {
+                // the piece holds four (gate, up) pairs: four outputs at columns n / 2 ..
+                if (m < a.M && n < a.N) {
+                    const kg_us8 h = __builtin_bit_cast(kg_us8, v);
+                    unsigned short o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = T::from_f(mm_silu_mul<DT>(T::to_f(h[2 * e]), T::to_f(h[2 * e + 1])));
+                    unsigned short* out = (unsigned short*)a.C + cb + (size_t)m * a.ldc + (n >> 1);
+                    if (n + 8 <= a.N && ((a.ldc | (n >> 1)) & 3) == 0) *(unsigned long long*)out = (unsigned long long)o[0] | ((unsigned long long)o[1] << 16) | ((unsigned long long)o[2] << 32) | ((unsigned long long)o[3] << 48);
+                    else for (int e = 0; e < 4 && n + 2 * e + 1 < a.N; ++e) out[e] = o[e];
+                }
+                continue;
+            }
+            if (!OUT_F32 && a.epi == MM_EPI_RESID && m < a.M && n < a.N) {
+                const unsigned short* rs = (const unsigned short*)a.resid + (size_t)m * a.ldr + n;
+                const kg_us8 h = __builtin_bit_cast(kg_us8, v);
+                unsigned short* out = (unsigned short*)a.C + cb + (size_t)m * a.ldc + n;
+                if (n + 8 <= a.N && ((a.ldc | a.ldr | n) & 7) == 0) {
+                    const kg_us8 r8 = __builtin_bit_cast(kg_us8, *(const kg_u4*)rs);
+                    kg_us8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = T::from_f(T::to_f(r8[e]) + T::to_f(h[e]));
+                    *(kg_u4*)out = __builtin_bit_cast(kg_u4, o);
+                } else {
+                    for (int e = 0; e < 8 && n + e < a.N; ++e) out[e] = T::from_f(T::to_f(rs[e]) + T::to_f(h[e]));
+                }
+                continue;
+            }
             if (m < a.M && n < a.N) {
                 char* out = (char*)a.C + (cb + (size_t)m * a.ldc + n) * ESZ;
                 if (n + 16 / ESZ <= a.N && (((a.ldc | n) * ESZ) & 15) == 0 && ((cb * ESZ) & 15) == 0) *(kg_u4*)out = v;
@@ -248,6 +281,7 @@ int kg_launch_mm(const KgMmArgs& a, int dtype, hipStream_t st) {
     if (a.causal < 0 || a.causal > 4 || (a.causal == 4 && a.b_packed != 2)) return -1;
     if (a.batch_inner < 1 || a.batch % a.batch_inner || a.b_inner_div < 1 || (a.sA2 & 7) || (a.sB2 & 7)) return -1;
     if (a.tile < 0 || a.tile > 2) return -1;
+    if (a.epi < 0 || a.epi > 2 || (a.epi && (a.out_f32 || a.batch != 1)) || (a.epi == MM_EPI_RESID && !a.resid) || (a.epi == MM_EPI_SILU_MUL && (a.N & 1))) return -1;
     if (dtype == KG_F16) { if (a.b_packed == 1) mm_launch<KG_F16, 1>(a, st); else if (a.b_packed == 2) mm_launch<KG_F16, 2>(a, st); else mm_launch<KG_F16, 0>(a, st); }
     else { if (a.b_packed == 1) mm_launch<KG_BF16, 1>(a, st); else if (a.b_packed == 2) mm_launch<KG_BF16, 2>(a, st); else mm_launch<KG_BF16, 0>(a, st); }
     return hipGetLastError() == hipSuccess ? 0 : -2;
