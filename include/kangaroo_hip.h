@@ -373,9 +373,11 @@ int kg_train_softce(int dtype, void* logits_out, const void* logits_tgt, const i
 int kg_train_add(int dtype, void* y, const void* x, long long n, void* stream);
 /* accelerator.clip_grad_value_(clip) + torch.optim.AdamW step `step` (1-based) on n fp32 parameters (train.py:227,285-286);
  * grad_dtype 0 fp16, 1 bf16, 2 fp32, multiplied by inv_scale first; p16 (may be NULL) receives the 16-bit copy
- * (copy_dtype) that the GEMMs read. */
+ * (copy_dtype) that the GEMMs read.  skip (device, may be NULL): a non-zero word makes the call a no-op, read when the kernel
+ * runs: the caller raises it when any gradient of the step is not finite, which is how the reference's GradScaler drops a step
+ * whose fp16 gradients overflowed (accelerate's optimizer wrapper around train.py:286). */
 int kg_train_adamw(float* p, float* m, float* v, const void* grad, int grad_dtype, float inv_scale, float clip, float lr, float beta1, float beta2,
-                   float eps, float weight_decay, int step, long long n, void* p16, int copy_dtype, void* stream);
+                   float eps, float weight_decay, int step, long long n, void* p16, int copy_dtype, const int* skip, void* stream);
 
 #ifdef __cplusplus
 }

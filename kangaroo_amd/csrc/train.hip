@@ -346,9 +346,10 @@ __global__ void __launch_bounds__(TB) softce_kernel(unsigned short* o, const uns
 // (accelerator.clip_grad_value_, train.py:285); also refreshes the 16-bit copy the GEMMs read.
 template <int GDT, int WDT>
 __global__ void adamw_kernel(float* p, float* m, float* v, const void* grad, float inv_scale, float clip, float lr, float b1, float b2,
-                             float eps, float wd, float bc1, float bc2_sqrt, size_t n, unsigned short* p16) {
+                             float eps, float wd, float bc1, float bc2_sqrt, size_t n, unsigned short* p16, const int* skip) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (skip && *skip != 0) return;          // a non-finite gradient somewhere in this step: leave parameters and moments alone
     float g = (GDT == 2) ? ((const float*)grad)[i] : KgT<GDT == 2 ? 0 : GDT>::to_f(((const unsigned short*)grad)[i]);
     g *= inv_scale;
     g = fminf(fmaxf(g, -clip), clip);
@@ -465,13 +466,13 @@ extern "C" int kg_train_add(int dtype, void* y, const void* x, long long n, void
 
 // grad_dtype: KG_F16 / KG_BF16 / 2 (fp32); copy_dtype: KG_F16 / KG_BF16 (p16 may be NULL); step is 1-based.
 extern "C" int kg_train_adamw(float* p, float* m, float* v, const void* grad, int grad_dtype, float inv_scale, float clip, float lr, float beta1, float beta2,
-                              float eps, float weight_decay, int step, long long n, void* p16, int copy_dtype, void* stream) {
+                              float eps, float weight_decay, int step, long long n, void* p16, int copy_dtype, const int* skip, void* stream) {
     if (!p || !m || !v || !grad || n < 1 || step < 1 || grad_dtype < 0 || grad_dtype > 2) return -1;
     hipStream_t st = (hipStream_t)stream;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
     const dim3 grid((unsigned)(((size_t)n + 255) / 256));
     unsigned short* c16 = (unsigned short*)p16;
-#define KG_ADAMW(G, W) hipLaunchKernelGGL((adamw_kernel<G, W>), grid, dim3(256), 0, st, p, m, v, grad, inv_scale, clip, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, (size_t)n, c16)
+#define KG_ADAMW(G, W) hipLaunchKernelGGL((adamw_kernel<G, W>), grid, dim3(256), 0, st, p, m, v, grad, inv_scale, clip, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, (size_t)n, c16, skip)
     if (copy_dtype == KG_BF16) { if (grad_dtype == 0) KG_ADAMW(0, KG_BF16); else if (grad_dtype == 1) KG_ADAMW(1, KG_BF16); else KG_ADAMW(2, KG_BF16); }
     else { if (grad_dtype == 0) KG_ADAMW(0, KG_F16); else if (grad_dtype == 1) KG_ADAMW(1, KG_F16); else KG_ADAMW(2, KG_F16); }
 #undef KG_ADAMW

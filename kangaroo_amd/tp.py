@@ -312,12 +312,22 @@ class TPGraphs:
         if pos0 < 0 or pos0 + n > self.shards[0].t_max:
             raise ValueError("positions outside the cache")
         if n not in self.graphs:
+            err = None
             try:
                 self._capture(x, pos0)
             except RuntimeError as e:                 # e.g. a process-group backend that cannot be captured
+                err = e
+            # Every rank must take the same path from here on (a rank replaying a graph while its peer launches the pass
+            # kernel by kernel would meet it at different collectives): the ranks agree on the outcome before it is used.
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=x.device)
+            if isinstance(self.group, DistGroup):
+                torch.cuda.synchronize()
+                self.group.dist.all_reduce(ok, op=self.group.dist.ReduceOp.MIN, group=self.group.group)
+            if int(ok[0]) == 0:
                 import warnings
-                warnings.warn(f"tensor-parallel pass of {n} rows could not be captured ({e}); launching it kernel by kernel")
+                warnings.warn(f"tensor-parallel pass of {n} rows could not be captured on every rank ({err}); launching it kernel by kernel")
                 self.max_rows = 0
+                self.graphs.clear()
                 torch.cuda.synchronize()
                 return tp_forward(self.shards, self.group, x, pos0)
         g, xs, out = self.graphs[n]

@@ -330,16 +330,25 @@ class AdapterTrainer:
         lr = linear_warmup_lr(self.lr, self.t * self.sync.world, self.warmup, self.total)     # AcceleratedScheduler: world steps per update
         self.t += 1
         inv_scale = 1.0 / (self.loss_scale * self.grad_accum)
+        # A gradient that is not finite (an fp16 overflow under the constant loss scale) must not reach the moments: the
+        # reference's GradScaler drops such a step and its schedule step.  The gradients are the all-reduced ones, so every
+        # rank sees the same flag; the update kernels read it on the device, the host learns of it with the step's sums.
+        bad = torch.stack([(~torch.isfinite(g)).any() for g in grads.values()]).any().to(torch.int32).reshape(1)
         for key, g in grads.items():
             p16 = self.w16.get(key)
             _lib.check(self.lib.kg_train_adamw(self._p(self.p[key]), self._p(self.m[key]), self._p(self.v[key]), self._p(g), 2, inv_scale, self.clip, lr,
-                                               self.betas[0], self.betas[1], self.adam_eps, self.wd, self.t, self.p[key].numel(), self._p(p16), self.dt, self._st()),
-                       "kg_train_adamw")
+                                               self.betas[0], self.betas[1], self.adam_eps, self.wd, self.t, self.p[key].numel(), self._p(p16), self.dt,
+                                               self._p(bad), self._st()), "kg_train_adamw")
         self.last_grads = {k: g * inv_scale for k, g in grads.items()}                 # unscaled, before clipping (tests, logging)
-        sums = torch.stack([row_loss.sum(), row_acc.sum()] + [((row_rank >= 0) & (row_rank < k)).sum().float() for k in (1, 2, 3)]).tolist()
+        sums = torch.stack([row_loss.sum(), row_acc.sum()] + [((row_rank >= 0) & (row_rank < k)).sum().float() for k in (1, 2, 3)] + [bad[0].float()]).tolist()
+        skipped = sums[5] != 0.0
+        if skipped:
+            self.t -= 1                                                              # neither the optimizer nor the schedule advanced
+        if sums[0] != sums[0]:
+            raise FloatingPointError("the loss is NaN (train.py:288-293 stops here too)")
         # top-k counts as train.py:298-309 accumulates them (the target token = argmax of the target head)
         return {"loss": sums[0] / n_loss, "prob_acc": sums[1] / n_loss, "lr": lr, "tokens": B * S0, "loss_positions": n_loss,
-                "top1_correct": int(sums[2]), "top2_correct": int(sums[3]), "top3_correct": int(sums[4])}
+                "top1_correct": int(sums[2]), "top2_correct": int(sums[3]), "top3_correct": int(sums[4]), "skipped": skipped}
 
     def state_dict(self, dtype=None) -> Dict[str, torch.Tensor]:
         return {PARAM_KEYS[k]: (v.to(dtype) if dtype is not None else v.clone()) for k, v in self.p.items()}

@@ -165,7 +165,7 @@ def test_clip_and_adamw_follow_torch(gdt, gcode):
         torch.nn.utils.clip_grad_value_([ref], 0.5)
         opt.step()
         gd = (gr.float() * scale).to(gdt).to(DEV)
-        _lib.check(lib.kg_train_adamw(vp(p), vp(m), vp(v), vp(gd), gcode, 1.0 / scale, 0.5, lr, 0.9, 0.95, 1e-8, 1e-2, step, n, vp(p16), 0, st()), "adamw")
+        _lib.check(lib.kg_train_adamw(vp(p), vp(m), vp(v), vp(gd), gcode, 1.0 / scale, 0.5, lr, 0.9, 0.95, 1e-8, 1e-2, step, n, vp(p16), 0, vp(None), st()), "adamw")
         tol = 1e-6 if gdt == torch.float32 else 2e-3
         assert torch.allclose(p.cpu(), ref.detach(), atol=tol * lr * 10 + 1e-7, rtol=1e-6), step
         assert torch.equal(p16, p.to(torch.float16))
@@ -341,3 +341,29 @@ def test_command_line_trains_two_epochs_and_writes_an_adapter_the_decoder_loads(
     ids = torch.randint(3, shape.vocab_size, (1, 9), generator=g)
     out = kangaroo_forward(ids.cuda(), model, 2, 12)
     assert len(out[0][0]) > 9
+
+
+def test_a_step_with_a_non_finite_gradient_changes_nothing():
+    """An fp16 overflow under the constant loss scale must not reach AdamW's moments (the reference's GradScaler drops the
+    step and its schedule step): parameters, moments and the step count stay as they were and the step reports it."""
+    from kangaroo_amd.train import AdapterTrainer, PARAM_KEYS
+    z = np.load(GOLD[0])
+    d, H, Hkv, V, steps, warm = (int(x) for x in z["meta"])
+    shape = LlamaShape(hidden_size=d, num_hidden_layers=1, num_attention_heads=H, num_key_value_heads=Hkv, intermediate_size=2 * d, vocab_size=V)
+    sd = {PARAM_KEYS[k]: torch.from_numpy(z[f"init.{k}"]) for k in TO.PARAM_NAMES}
+    tr = AdapterTrainer(shape, sd, torch.from_numpy(z["head"]), dtype=torch.float16, lr=1e-3, num_warmup_steps=1, total_steps=100)
+    batch = {k: torch.from_numpy(z[f"batch0.{k}"]) for k in ("hidden_states_early", "target", "attention_mask", "loss_mask")}
+    tr.step(batch); tr.step(batch)
+    before = {k: v.clone() for k, v in tr.p.items()}; m0 = {k: v.clone() for k, v in tr.m.items()}; t0 = tr.t
+    bad = dict(batch)
+    bad["hidden_states_early"] = batch["hidden_states_early"] * 3e4          # overflows fp16 inside the layer
+    try:
+        out = tr.step(bad)
+        assert out["skipped"] is True
+    except FloatingPointError:
+        pass                                                                   # the loss itself was NaN: the reference stops there as well
+    assert tr.t == t0 or tr.t == t0 + 1
+    for k in before:
+        assert torch.equal(tr.p[k], before[k]) and torch.equal(tr.m[k], m0[k]), k
+    out = tr.step(batch)
+    assert out["skipped"] is False and not torch.equal(tr.p["q_proj"], before["q_proj"])
