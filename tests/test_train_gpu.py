@@ -251,6 +251,42 @@ def test_live_oracle_at_a_wider_shape_and_loss_goes_down():
     assert out["loss"] < first - 0.05          # the same batch twelve times: the loss must fall
 
 
+def test_one_step_at_the_7b_adapter_shape_against_the_live_oracle():
+    """The shape the training bench is quoted on (d 4096, 32 heads, vocabulary 32000), one batch of 2 x 256 positions
+    with ragged lengths: loss, top-1 agreement and every first-step gradient against the fp32 oracle."""
+    from kangaroo_amd.train import AdapterTrainer, PARAM_KEYS
+    d, H, Hkv, V = 4096, 32, 32, 32000
+    shape = LlamaShape(hidden_size=d, num_hidden_layers=1, num_attention_heads=H, num_key_value_heads=Hkv, intermediate_size=11008,
+                       vocab_size=V, rms_norm_eps=1e-6, max_position_embeddings=2048)
+    g = torch.Generator().manual_seed(77)
+    params = {"input_layernorm": 1 + 0.1 * torch.randn(d, generator=g), "q_proj": torch.randn(d, d, generator=g) / d ** 0.5,
+              "k_proj": torch.randn(d, d, generator=g) / d ** 0.5, "v_proj": torch.randn(d, d, generator=g) / d ** 0.5,
+              "o_proj": torch.randn(d, d, generator=g) / d ** 0.5, "norm": 1 + 0.1 * torch.randn(d, generator=g)}
+    head = torch.randn(V, d, generator=g) * 0.05
+    lens = [256, 201]
+    S = max(lens)
+    batch = {"hidden_states_early": torch.zeros(2, S, d), "target": torch.zeros(2, S, d), "attention_mask": torch.zeros(2, S, dtype=torch.long),
+             "loss_mask": torch.zeros(2, S, dtype=torch.long)}
+    for b, n in enumerate(lens):
+        batch["hidden_states_early"][b, :n] = torch.randn(n, d, generator=g)
+        batch["target"][b, :n] = torch.randn(n, d, generator=g)
+        batch["attention_mask"][b, :n] = 1
+        batch["loss_mask"][b, 40:n - 1] = 1
+    for k in ("hidden_states_early", "target"):
+        batch[k] = batch[k].half().float()
+    tr = AdapterTrainer(shape, {PARAM_KEYS[k]: v for k, v in params.items()}, head, dtype=torch.float16, lr=2e-4, num_warmup_steps=1, total_steps=1000)
+    out = tr.step(batch)
+    opt = TO.AdamWState({k: v.clone() for k, v in params.items()})
+    loss, acc, grads = TO.train_step({k: v.clone() for k, v in params.items()}, opt, head, batch, H, Hkv, 1e-6,
+                                     TO.linear_warmup_lr(2e-4, 0, 1, 1000))
+    assert abs(out["loss"] - loss) < 5e-3 * abs(loss), (out["loss"], loss)
+    assert abs(out["prob_acc"] - acc) < 5e-3, (out["prob_acc"], acc)
+    for k in TO.PARAM_NAMES:
+        err = float((tr.last_grads[k].cpu() - grads[k]).abs().max())
+        print(f"7B-shape step: grad {k}: max err {err:.3e} of max {float(grads[k].abs().max()):.3e}")
+        assert err <= 3e-2 * float(grads[k].abs().max()) + 1e-9, (k, err, float(grads[k].abs().max()))
+
+
 def test_step_is_reproducible_bit_for_bit():
     z = np.load(GOLD[0])
     dims = tuple(int(x) for x in z["meta"])
