@@ -137,7 +137,7 @@ struct KgMmArgs {
                                         // 3: A is upper triangular: K is walked from the tile's first row on;
                                         // 4: a K-major B whose row k ends at column k: K is walked from the tile's first column on
     float alpha;
-    int tile;                           // 0: chosen by size; 1: 128 x 128 tiles; 2: 256 x 256 tiles (measurements)
+    int tile;                           // 0: chosen by size; measurements: 1: 128 x 128 tiles; 2: 256 x 256, staged through registers; 3: 256 x 256, loads write LDS
     // 16-bit output only.  epi 1: C = round16(resid + round16(A.B^T)) (the residual add of a decoder layer, resid rows ldr
     // elements apart); epi 2: columns (2i, 2i+1) hold (gate_i, up_i) and C[m][i] = silu(gate) * up with the reference's
     // roundings (N / 2 output columns, ldc counts those)

@@ -29,6 +29,7 @@
 // band of 8 tile rows: they share the L2 copies of that band's A rows and of the B columns they walk.
 #include "kg_common.h"
 #include "kg_kernels.h"
+#include <type_traits>
 
 #define MM_BK 64
 
@@ -41,6 +42,97 @@ template <int DT> __device__ __forceinline__ float mm_silu_mul(float g, float u)
     return kg_round<DT>(s * u);
 }
 __device__ __forceinline__ unsigned mm_kmajor_key(int k) { return (unsigned)((k & 3) | (((k >> 3) & 1) << 2)); }
+
+// Tiles are dealt so that the blocks that share an XCD (block index mod 8) take consecutive tiles (bijective for any tile
+// count) of a band of 8 tile rows.
+template <int BM, int BN>
+__device__ __forceinline__ void mm_block_tile(const KgMmArgs& a, int& m0, int& n0) {
+    const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN, nt = tm * tn;
+    int id = blockIdx.x;
+    {
+        const int q = nt >> 3, r = nt & 7, x = id & 7;
+        id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+    }
+    const int band = id / (8 * tn), in_band = id - band * 8 * tn;
+    const int band_rows = min(8, tm - band * 8);
+    m0 = (band * 8 + in_band % band_rows) * BM; n0 = (in_band / band_rows) * BN;
+}
+
+// The epilogue of a tile: the wave's part goes through its own LDS region and leaves in whole rows (a lane's accumulators
+// are 4 columns of 16 different rows: stored directly, every wave-level store would touch 16 rows with 32 bytes each).
+// Every wave of the block must be past its last LDS read of the pipeline, and no write to LDS may be in flight.
+template <int DT, int BM, int BN, int WM, int WN, bool OUT_F32>
+__device__ __forceinline__ void mm_epilogue(const KgMmArgs& a, kg_f4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int m0, int n0, int zo, int zi,
+                                            int wave, int lane) {
+    typedef KgT<DT> T;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    const int wr = wave / WN, wc = wave % WN, fr = lane & 15, fg = lane >> 4;
+    const size_t cb = (size_t)zo * a.sC + (size_t)zi * a.sC2;
+    constexpr int WROWS = BM / WM, WCOLS = BN / WN;              // the wave's part of the tile
+    constexpr int ESZ = OUT_F32 ? 4 : 2;
+    constexpr int ROWB = WCOLS * ESZ + 16;                       // padded row of the staging image (keeps 16-byte alignment, staggers banks)
+    static_assert((size_t)WM * WN * 16 * ROWB <= 2 * (size_t)(BM + BN) * MM_BK * 2, "staging image fits the pipeline's LDS");
+    char* stg = smem + wave * 16 * ROWB;                         // 16 rows at a time
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        // all waves are past the last step's barrier; a wave only touches its own region from here on
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            kg_f4 v = acc[i][j];
+            if (a.alpha != 1.0f) v = v * a.alpha;
+            char* dst = stg + fr * ROWB + (16 * j + 4 * fg) * ESZ;
+            if (OUT_F32) *(kg_f4*)dst = v;
+            else *(unsigned long long*)dst = (unsigned long long)T::from_f(v[0]) | ((unsigned long long)T::from_f(v[1]) << 16) | ((unsigned long long)T::from_f(v[2]) << 32) | ((unsigned long long)T::from_f(v[3]) << 48);
+        }
+        // 16 rows x WCOLS elements: 16-byte pieces, consecutive lanes along a row
+        constexpr int PPR = WCOLS * ESZ / 16, NP = 16 * PPR;     // pieces per row, pieces of the 16 rows
+#pragma unroll
+        for (int c = lane; c < NP; c += 64) {
+            const int r = c / PPR, pc = c - r * PPR;
+            const int m = m0 + wr * WROWS + 16 * i + r, n = n0 + wc * WCOLS + pc * (16 / ESZ);
+            const kg_u4 v = *(const kg_u4*)(stg + r * ROWB + pc * 16);
+            if (!OUT_F32 && a.epi == MM_EPI_SILU_MUL) {
+                // the piece holds four (gate, up) pairs: four outputs at columns n / 2 ..
+                if (m < a.M && n < a.N) {
+                    const kg_us8 h = __builtin_bit_cast(kg_us8, v);
+                    unsigned short o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = T::from_f(mm_silu_mul<DT>(T::to_f(h[2 * e]), T::to_f(h[2 * e + 1])));
+                    unsigned short* out = (unsigned short*)a.C + cb + (size_t)m * a.ldc + (n >> 1);
+                    if (n + 8 <= a.N && ((a.ldc | (n >> 1)) & 3) == 0) *(unsigned long long*)out = (unsigned long long)o[0] | ((unsigned long long)o[1] << 16) | ((unsigned long long)o[2] << 32) | ((unsigned long long)o[3] << 48);
+                    else for (int e = 0; e < 4 && n + 2 * e + 1 < a.N; ++e) out[e] = o[e];
+                }
+                continue;
+            }
+            if (!OUT_F32 && a.epi == MM_EPI_RESID && m < a.M && n < a.N) {
+                const unsigned short* rs = (const unsigned short*)a.resid + (size_t)m * a.ldr + n;
+                const kg_us8 h = __builtin_bit_cast(kg_us8, v);
+                unsigned short* out = (unsigned short*)a.C + cb + (size_t)m * a.ldc + n;
+                if (n + 8 <= a.N && ((a.ldc | a.ldr | n) & 7) == 0) {
+                    const kg_us8 r8 = __builtin_bit_cast(kg_us8, *(const kg_u4*)rs);
+                    kg_us8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = T::from_f(T::to_f(r8[e]) + T::to_f(h[e]));
+                    *(kg_u4*)out = __builtin_bit_cast(kg_u4, o);
+                } else {
+                    for (int e = 0; e < 8 && n + e < a.N; ++e) out[e] = T::from_f(T::to_f(rs[e]) + T::to_f(h[e]));
+                }
+                continue;
+            }
+            if (m < a.M && n < a.N) {
+                char* out = (char*)a.C + (cb + (size_t)m * a.ldc + n) * ESZ;
+                if (n + 16 / ESZ <= a.N && (((a.ldc | n) * ESZ) & 15) == 0 && ((cb * ESZ) & 15) == 0) *(kg_u4*)out = v;
+                else {
+                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                    for (int e = 0; e < 16 / ESZ && n + e < a.N; ++e) {
+                        if (OUT_F32) ((float*)out)[e] = __builtin_bit_cast(float, w[e]);
+                        else ((unsigned short*)out)[e] = (unsigned short)(w[e >> 1] >> (16 * (e & 1)));
+                    }
+                }
+            }
+        }
+    }
+}
 
 // BMODE 0: B [N][K] row-major; 1: B in the packed tile layout; 2: B [K][N] (K-major)
 template <int DT, int BM, int BN, int WM, int WN, int BMODE, bool OUT_F32>
@@ -57,16 +149,8 @@ __global__ void __launch_bounds__(WM * WN * 64) kg_mm_kernel(const KgMmArgs a) {
     const int fr = lane & 15, fg = lane >> 4;
 
     // ---- tile of this block ----
-    const int tm = (a.M + MM_BM - 1) / MM_BM, tn = (a.N + MM_BN - 1) / MM_BN, nt = tm * tn;
-    int id = blockIdx.x;
-    {   // blocks that share an XCD (index mod 8) take consecutive tiles (bijective for any tile count)
-        const int q = nt >> 3, r = nt & 7, x = id & 7;
-        id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
-    }
-    const int band = id / (8 * tn), in_band = id - band * 8 * tn;
-    const int band_rows = min(8, tm - band * 8);
-    const int tile_m = band * 8 + in_band % band_rows, tile_n = in_band / band_rows;
-    const int m0 = tile_m * MM_BM, n0 = tile_n * MM_BN;
+    int m0, n0;
+    mm_block_tile<BM, BN>(a, m0, n0);
     if (a.causal == 1 && n0 > m0 + MM_BM - 1) return;                  // output tile entirely above the diagonal: never read
     const int zo = (int)blockIdx.z / a.batch_inner, zi = (int)blockIdx.z - zo * a.batch_inner;
     const unsigned short* Ab = (const unsigned short*)a.A + (size_t)zo * a.sA + (size_t)zi * a.sA2;
@@ -181,74 +265,164 @@ __global__ void __launch_bounds__(WM * WN * 64) kg_mm_kernel(const KgMmArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: the wave's part goes through its own LDS region and leaves in whole rows ----
-    // (a lane's accumulators are 4 columns of 16 different rows: stored directly, every wave-level store would touch 16 rows
-    //  with 32 bytes each)
-    const size_t cb = (size_t)zo * a.sC + (size_t)zi * a.sC2;
-    constexpr int WROWS = BM / WM, WCOLS = BN / WN;              // the wave's part of the tile
-    constexpr int ESZ = OUT_F32 ? 4 : 2;
-    constexpr int ROWB = WCOLS * ESZ + 16;                       // padded row of the staging image (keeps 16-byte alignment, staggers banks)
-    static_assert((size_t)WM * WN * 16 * ROWB <= 2 * (size_t)(BM + BN) * MM_BK * 2, "staging image fits the pipeline's LDS");
-    char* stg = smem + wave * 16 * ROWB;                         // 16 rows at a time
+    mm_epilogue<DT, BM, BN, WM, WN, OUT_F32>(a, acc, smem, m0, n0, zo, zi, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The 256 x 256 tile again, built for the case that decides the large products: one block per CU, two waves per SIMD.
+// A K step of 64 is staged as four half tiles of 16 KB (128 rows x 128 bytes) by buffer loads that write LDS directly
+// (no register stop, no ds_write pass): the LDS destination of such a load is the wave's base + lane * 16, so the image is
+// linear and the XOR swizzle of the fragment reads sits on the SOURCE address of each lane instead.  Rows are assigned to
+// half tiles by the phase that reads them: A_0 / A_1 hold the first / second 64 rows of both wave rows' parts, B_0 / B_1 the
+// first / second 32 columns of all four wave columns' parts.  A step is four phases, one 64 x 32 quadrant of the wave's
+// 128 x 64 part each (16 MFMAs between two block barriers):
+//     phase 0  reads A_0, B_0   quadrant (0,0)        phase 2  reads A_1   quadrant (1,1)
+//     phase 1  reads B_1        quadrant (0,1)        phase 3  -            quadrant (1,0)   (B_0 stays in registers)
+// so every half tile is read in exactly one phase and can be refilled two phases later.  Every phase requests the half tile
+// that is read six phases on and then waits until at most four half tiles (8 loads per thread) are outstanding: what the
+// NEXT phase reads has then landed, and the barrier that follows makes that true of every wave's share.  The loads are
+// never drained inside the loop.  The two wave rows run one barrier apart, so that on every SIMD one wave is in its MFMA
+// cluster while the other issues its LDS reads and loads.  Half tiles past the last step are requested out of range
+// (nothing is fetched) so that the counts stay uniform.
+// ---------------------------------------------------------------------------------------------------------------------
+#define MM8_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define MM8_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int DT, int BMODE, bool OUT_F32>
+__global__ void __launch_bounds__(512) kg_mm8_kernel(const KgMmArgs a) {
+    static_assert(BMODE == 0 || BMODE == 1, "row-major or packed B");
+    typedef KgT<DT> T;
+    constexpr int BM = 256, BN = 256, WM = 2, WN = 4;
+    constexpr int HALF = 128 * 128, BUF = 4 * HALF;                 // bytes: a half tile, one step's four half tiles
+    constexpr int OFF_A0 = 0, OFF_A1 = HALF, OFF_B0 = 2 * HALF, OFF_B1 = 3 * HALF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    int m0, n0;
+    mm_block_tile<BM, BN>(a, m0, n0);
+    if (a.causal == 1 && n0 > m0 + BM - 1) return;
+    const int zo = (int)blockIdx.z / a.batch_inner, zi = (int)blockIdx.z - zo * a.batch_inner;
+    const unsigned short* Ab = (const unsigned short*)a.A + (size_t)zo * a.sA + (size_t)zi * a.sA2;
+    const unsigned short* Bb = (const unsigned short*)a.B + (size_t)zo * a.sB + (size_t)(zi / a.b_inner_div) * a.sB2;
+    const size_t a_bytes = ((size_t)(a.M - 1) * a.lda + a.K) * 2;
+    const size_t b_bytes = BMODE == 1 ? (size_t)((a.N + 15) / 16) * (a.K / 32) * 1024 : ((size_t)(a.N - 1) * a.ldb + a.K) * 2;
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)(a_bytes > 0x7fffffffu ? 0x7fffffffu : a_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)(b_bytes > 0x7fffffffu ? 0x7fffffffu : b_bytes), 0x00020000);
+    const int k_end = (a.causal == 2) ? min(a.K, m0 + BM) : a.K;
+    const int kt0 = (a.causal == 3) ? m0 / MM_BK : 0;
+    const int KT = (k_end + MM_BK - 1) / MM_BK - kt0;
+
+    // ---- sources: load g (0, 1) of a half tile fills LDS rows 8 (8 g + wave) .. + 7, lane l row l >> 3, 16-byte slot l & 7 ----
+    unsigned a_src[2][2], b_src[2][2];      // [half][g]: byte offset at k0 = 0 (0xFFFFFFFF: row out of range)
+    int src_k[2];                           // first k of the lane's piece inside a step
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        // all waves are past the last step's barrier; a wave only touches its own region from here on
+    for (int g = 0; g < 2; ++g) {
+        const int q = (8 * g + wave) * 8 + (lane >> 3), ch = (lane & 7) ^ ((q >> 1) & 7);
+        src_k[g] = 8 * ch;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            kg_f4 v = acc[i][j];
-            if (a.alpha != 1.0f) v = v * a.alpha;
-            char* dst = stg + fr * ROWB + (16 * j + 4 * fg) * ESZ;
-            if (OUT_F32) *(kg_f4*)dst = v;
-            else *(unsigned long long*)dst = (unsigned long long)T::from_f(v[0]) | ((unsigned long long)T::from_f(v[1]) << 16) | ((unsigned long long)T::from_f(v[2]) << 32) | ((unsigned long long)T::from_f(v[3]) << 48);
-        }
-        // 16 rows x WCOLS elements: 16-byte pieces, consecutive lanes along a row
-        constexpr int PPR = WCOLS * ESZ / 16, NP = 16 * PPR;     // pieces per row, pieces of the 16 rows
-#pragma unroll
-        for (int c = lane; c < NP; c += 64) {
-            const int r = c / PPR, pc = c - r * PPR;
-            const int m = m0 + wr * WROWS + 16 * i + r, n = n0 + wc * WCOLS + pc * (16 / ESZ);
-            const kg_u4 v = *(const kg_u4*)(stg + r * ROWB + pc * 16);
-            if (!OUT_F32 && a.epi == MM_EPI_SILU_MUL) {
-                // the piece holds four (gate, up) pairs: four outputs at columns n / 2 ..
-                if (m < a.M && n < a.N) {
-                    const kg_us8 h = __builtin_bit_cast(kg_us8, v);
-                    unsigned short o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = T::from_f(mm_silu_mul<DT>(T::to_f(h[2 * e]), T::to_f(h[2 * e + 1])));
-                    unsigned short* out = (unsigned short*)a.C + cb + (size_t)m * a.ldc + (n >> 1);
-                    if (n + 8 <= a.N && ((a.ldc | (n >> 1)) & 3) == 0) *(unsigned long long*)out = (unsigned long long)o[0] | ((unsigned long long)o[1] << 16) | ((unsigned long long)o[2] << 32) | ((unsigned long long)o[3] << 48);
-                    else for (int e = 0; e < 4 && n + 2 * e + 1 < a.N; ++e) out[e] = o[e];
-                }
-                continue;
-            }
-            if (!OUT_F32 && a.epi == MM_EPI_RESID && m < a.M && n < a.N) {
-                const unsigned short* rs = (const unsigned short*)a.resid + (size_t)m * a.ldr + n;
-                const kg_us8 h = __builtin_bit_cast(kg_us8, v);
-                unsigned short* out = (unsigned short*)a.C + cb + (size_t)m * a.ldc + n;
-                if (n + 8 <= a.N && ((a.ldc | a.ldr | n) & 7) == 0) {
-                    const kg_us8 r8 = __builtin_bit_cast(kg_us8, *(const kg_u4*)rs);
-                    kg_us8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = T::from_f(T::to_f(r8[e]) + T::to_f(h[e]));
-                    *(kg_u4*)out = __builtin_bit_cast(kg_u4, o);
-                } else {
-                    for (int e = 0; e < 8 && n + e < a.N; ++e) out[e] = T::from_f(T::to_f(rs[e]) + T::to_f(h[e]));
-                }
-                continue;
-            }
-            if (m < a.M && n < a.N) {
-                char* out = (char*)a.C + (cb + (size_t)m * a.ldc + n) * ESZ;
-                if (n + 16 / ESZ <= a.N && (((a.ldc | n) * ESZ) & 15) == 0 && ((cb * ESZ) & 15) == 0) *(kg_u4*)out = v;
-                else {
-                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
-                    for (int e = 0; e < 16 / ESZ && n + e < a.N; ++e) {
-                        if (OUT_F32) ((float*)out)[e] = __builtin_bit_cast(float, w[e]);
-                        else ((unsigned short*)out)[e] = (unsigned short)(w[e >> 1] >> (16 * (e & 1)));
-                    }
-                }
-            }
+        for (int h = 0; h < 2; ++h) {
+            const int row = m0 + (q >> 6) * 128 + h * 64 + (q & 63);
+            a_src[h][g] = row < a.M ? (unsigned)(((size_t)row * a.lda + 8 * ch) * 2) : 0xFFFFFFFFu;
+            const int n = n0 + (q >> 5) * 64 + h * 32 + (q & 31);
+            if (BMODE == 1) b_src[h][g] = n < a.N ? (unsigned)((((size_t)(n >> 4) * (a.K >> 5) + (ch >> 2)) * 512 + (ch & 3) * 128 + (n & 15) * 8) * 2) : 0xFFFFFFFFu;
+            else b_src[h][g] = n < a.N ? (unsigned)(((size_t)n * a.ldb + 8 * ch) * 2) : 0xFFFFFFFFu;
         }
     }
+    // half tile `off` (compile-time LDS offset) of step u: two loads per thread, whatever u
+    auto request = [&](char* dst, const unsigned (&src)[2], const __amdgpu_buffer_rsrc_t& rs, bool is_b, int u) {
+        const int k0 = (kt0 + u) * MM_BK;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const bool ok = u < KT && k0 + src_k[g] < k_end && src[g] != 0xFFFFFFFFu;
+            const unsigned adv = (BMODE == 1 && is_b) ? (unsigned)((k0 >> 5) * 1024) : (unsigned)(k0 * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + (8 * g + wave) * 1024), 16,
+                                                     ok ? src[g] + adv : 0xFFFFFFFFu, 0, 0, 0);
+        }
+    };
+
+    kg_f4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = kg_f4{0.f, 0.f, 0.f, 0.f};
+    kg_u4 fa[4][2], fb0[2][2], fb1[2][2];   // [tile][k half of the step]
+
+    auto read_a = [&](const char* half) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = *(const kg_u4*)(half + mm_lds_off(wr * 64 + 16 * i + fr, 4 * ks + fg));
+    };
+    auto read_b = [&](const char* half, kg_u4 (&fb)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb[j][ks] = *(const kg_u4*)(half + mm_lds_off(wc * 32 + 16 * j + fr, 4 * ks + fg));
+    };
+    auto cluster = [&](auto mh_c, auto nh_c, const kg_u4 (&fb)[2][2]) {
+        constexpr int MH = decltype(mh_c)::value, NH = decltype(nh_c)::value;
+        MM8_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[4 * MH + i][2 * NH + j] = T::mfma(fb[j][ks], fa[i][ks], acc[4 * MH + i][2 * NH + j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    // one step out of buffer B (compile time); t is the step's number
+    auto step = [&](auto b_c, int t) {
+        constexpr int B = decltype(b_c)::value;
+        char* cur = smem + B * BUF;
+        char* oth = smem + (B ^ 1) * BUF;
+        // phase 0
+        read_b(cur + OFF_B0, fb0); __builtin_amdgcn_sched_barrier(0); read_a(cur + OFF_A0);
+        request(oth + OFF_B1, b_src[1], br, true, t + 1);
+        MM8_WAIT_VM(8); __builtin_amdgcn_s_barrier();
+        cluster(I0(), I0(), fb0);
+        __builtin_amdgcn_s_barrier();
+        // phase 1
+        read_b(cur + OFF_B1, fb1);
+        request(oth + OFF_A1, a_src[1], ar, false, t + 1);
+        MM8_WAIT_VM(8); __builtin_amdgcn_s_barrier();
+        cluster(I0(), I1(), fb1);
+        __builtin_amdgcn_s_barrier();
+        // phase 2
+        read_a(cur + OFF_A1);
+        request(cur + OFF_A0, a_src[0], ar, false, t + 2);
+        MM8_WAIT_VM(8); __builtin_amdgcn_s_barrier();
+        cluster(I1(), I1(), fb1);
+        __builtin_amdgcn_s_barrier();
+        // phase 3
+        request(cur + OFF_B0, b_src[0], br, true, t + 2);
+        MM8_WAIT_VM(8); __builtin_amdgcn_s_barrier();
+        cluster(I1(), I0(), fb0);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // ---- six half tiles ahead: all of step 0, A_0 and B_0 of step 1 ----
+    request(smem + OFF_A0, a_src[0], ar, false, 0);
+    request(smem + OFF_B0, b_src[0], br, true, 0);
+    request(smem + OFF_B1, b_src[1], br, true, 0);
+    request(smem + OFF_A1, a_src[1], ar, false, 0);
+    request(smem + BUF + OFF_A0, a_src[0], ar, false, 1);
+    request(smem + BUF + OFF_B0, b_src[0], br, true, 1);
+    MM8_WAIT_VM(8); __builtin_amdgcn_s_barrier();        // A_0 and B_0 of step 0 are in LDS, every wave's share
+    if (wr == 1) __builtin_amdgcn_s_barrier();            // the second wave row runs one barrier behind
+    int t = 0;
+    for (; t + 1 < KT; t += 2) { step(I0(), t); step(I1(), t + 1); }
+    if (t < KT) step(I0(), t);
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    MM8_WAIT_VM(0);                                       // the requests past the last step
+    __builtin_amdgcn_s_barrier();
+    mm_epilogue<DT, BM, BN, WM, WN, OUT_F32>(a, acc, smem, m0, n0, zo, zi, wave, lane);
 }
 
 static int g_mm_ncu = 256;
@@ -267,8 +441,13 @@ static void mm_launch(const KgMmArgs& a, hipStream_t st) {
     // 8192 x 4096 x 4096 is 296 us against 410 us (model 0.71), 640 x 22016 x 4096 232 against 167 us.
     const double t_big = (double)(((long)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.batch + g_mm_ncu - 1) / g_mm_ncu) * (65536.0 / 1.4);
     const double t_small = (double)(((long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch + 2 * g_mm_ncu - 1) / (2 * g_mm_ncu)) * (16384.0 / 0.5);
-    const bool big = a.tile == 2 || (a.tile == 0 && t_big < t_small);
-    if (big) mm_launch_tile<DT, 256, 256, 2, 4, BMODE>(a, st);
+    const bool big = a.tile >= 2 || (a.tile == 0 && t_big < t_small);
+    if (big && a.tile != 2 && BMODE != 2) {               // the large tile's direct-to-LDS form (a.tile == 2 asks for the register-staged one)
+        constexpr int BM8 = BMODE == 2 ? 0 : BMODE;
+        const dim3 grid(((a.M + 255) / 256) * ((a.N + 255) / 256), 1, a.batch), block(512);
+        if (a.out_f32) hipLaunchKernelGGL((kg_mm8_kernel<DT, BM8, true>), grid, block, 131072, st, a);
+        else hipLaunchKernelGGL((kg_mm8_kernel<DT, BM8, false>), grid, block, 131072, st, a);
+    } else if (big) mm_launch_tile<DT, 256, 256, 2, 4, BMODE>(a, st);
     else mm_launch_tile<DT, 128, 128, 2, 2, BMODE>(a, st);
 }
 
@@ -280,7 +459,7 @@ int kg_launch_mm(const KgMmArgs& a, int dtype, hipStream_t st) {
     if (a.b_packed == 2 && (a.N & 7)) return -1;
     if (a.causal < 0 || a.causal > 4 || (a.causal == 4 && a.b_packed != 2)) return -1;
     if (a.batch_inner < 1 || a.batch % a.batch_inner || a.b_inner_div < 1 || (a.sA2 & 7) || (a.sB2 & 7)) return -1;
-    if (a.tile < 0 || a.tile > 2) return -1;
+    if (a.tile < 0 || a.tile > 3) return -1;
     if (a.epi < 0 || a.epi > 2 || (a.epi && (a.out_f32 || a.batch != 1)) || (a.epi == MM_EPI_RESID && !a.resid) || (a.epi == MM_EPI_SILU_MUL && (a.N & 1))) return -1;
     if (dtype == KG_F16) { if (a.b_packed == 1) mm_launch<KG_F16, 1>(a, st); else if (a.b_packed == 2) mm_launch<KG_F16, 2>(a, st); else mm_launch<KG_F16, 0>(a, st); }
     else { if (a.b_packed == 1) mm_launch<KG_BF16, 1>(a, st); else if (a.b_packed == 2) mm_launch<KG_BF16, 2>(a, st); else mm_launch<KG_BF16, 0>(a, st); }
@@ -290,6 +469,7 @@ int kg_launch_mm(const KgMmArgs& a, int dtype, hipStream_t st) {
 template <int DT, int P, bool F> static void mm_attr() {
     (void)hipFuncSetAttribute((const void*)kg_mm_kernel<DT, 128, 128, 2, 2, P, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * MM_BK * 2);
     (void)hipFuncSetAttribute((const void*)kg_mm_kernel<DT, 256, 256, 2, 4, P, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * MM_BK * 2);
+    if (P != 2) (void)hipFuncSetAttribute((const void*)kg_mm8_kernel<DT, (P == 2 ? 0 : P), F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
 }
 void kg_mm_init() {
     int dev = 0, ncu = 0;

@@ -87,6 +87,13 @@ for name, (M, N, K), batch in (("projection 8192x4096x4096", (8192, 4096, 4096),
     A = (torch.rand(shp, device=dev, generator=g) * 2 - 1).to(dt)
     B = (torch.rand((batch, N, K) if batch > 1 else (N, K), device=dev, generator=g) * 2 - 1).to(dt)
     fl = 2.0 * M * N * K * batch
-    t_own = timeit(lambda: mm(A, B))
-    t_lib = timeit(lambda: torch.matmul(A, B.transpose(-1, -2)))
-    print(f"{name:40s} own {t_own * 1e3:8.1f} us {fl / t_own / 1e9:7.0f} TFLOP/s   library {t_lib * 1e3:8.1f} us {fl / t_lib / 1e9:7.0f} TFLOP/s", flush=True)
+    res = {}
+    for rnd in range(2):                                   # interleaved rounds in one process; the better of the two
+        for tile in ("1", "2", "3"):                       # 128 x 128, 256 x 256 register-staged, 256 x 256 direct-to-LDS
+            os.environ["KG_MM_TILE"] = tile
+            res[tile] = min(res.get(tile, 1e9), timeit(lambda: mm(A, B)))
+        res["lib"] = min(res.get("lib", 1e9), timeit(lambda: torch.matmul(A, B.transpose(-1, -2))))
+    os.environ.pop("KG_MM_TILE")
+    t_auto = timeit(lambda: mm(A, B))
+    tf = lambda t: fl / t / 1e9
+    print(f"{name:40s} 128^2 {tf(res['1']):6.0f}  256^2 reg {tf(res['2']):6.0f}  256^2 lds {tf(res['3']):6.0f}  chosen {tf(t_auto):6.0f} ({t_auto * 1e3:7.1f} us)   library {tf(res['lib']):6.0f} TFLOP/s", flush=True)
