@@ -316,18 +316,24 @@ __global__ void __launch_bounds__(512) kg_mm8_kernel(const KgMmArgs a) {
 
     // ---- sources: load g (0, 1) of a half tile fills LDS rows 8 (8 g + wave) .. + 7, lane l row l >> 3, 16-byte slot l & 7 ----
     unsigned a_src[2][2], b_src[2][2];      // [half][g]: byte offset at k0 = 0 (0xFFFFFFFF: row out of range)
-    int src_k[2];                           // first k of the lane's piece inside a step
+    int a_k[2], b_k[2];                     // first k of the lane's piece inside a step
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int q = (8 * g + wave) * 8 + (lane >> 3), ch = (lane & 7) ^ ((q >> 1) & 7);
-        src_k[g] = 8 * ch;
+        a_k[g] = 8 * ch; b_k[g] = BMODE == 1 ? 32 * (wave & 1) + 8 * (lane >> 4) : 8 * ch;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int row = m0 + (q >> 6) * 128 + h * 64 + (q & 63);
             a_src[h][g] = row < a.M ? (unsigned)(((size_t)row * a.lda + 8 * ch) * 2) : 0xFFFFFFFFu;
-            const int n = n0 + (q >> 5) * 64 + h * 32 + (q & 31);
-            if (BMODE == 1) b_src[h][g] = n < a.N ? (unsigned)((((size_t)(n >> 4) * (a.K >> 5) + (ch >> 2)) * 512 + (ch & 3) * 128 + (n & 15) * 8) * 2) : 0xFFFFFFFFu;
-            else b_src[h][g] = n < a.N ? (unsigned)(((size_t)n * a.ldb + 8 * ch) * 2) : 0xFFFFFFFFu;
+            if (BMODE == 1) {
+                // packed B: the half tile's LDS image is the 16 packed tiles themselves (8 row groups x 2 k tiles of 1 KiB), load g of
+                // wave w copies tile 8 g + w whole: 1 KiB of consecutive memory, and a fragment read is 1 KiB of consecutive LDS
+                const int idx = 8 * g + wave, rgl = idx >> 1, n = n0 + (rgl >> 1) * 64 + h * 32 + (rgl & 1) * 16;
+                b_src[h][g] = n < a.N ? (unsigned)((((size_t)(n >> 4) * (a.K >> 5) + (idx & 1)) * 512 + lane * 8) * 2) : 0xFFFFFFFFu;
+            } else {
+                const int n = n0 + (q >> 5) * 64 + h * 32 + (q & 31);
+                b_src[h][g] = n < a.N ? (unsigned)(((size_t)n * a.ldb + 8 * ch) * 2) : 0xFFFFFFFFu;
+            }
         }
     }
     // half tile `off` (compile-time LDS offset) of step u: two loads per thread, whatever u
@@ -335,7 +341,7 @@ __global__ void __launch_bounds__(512) kg_mm8_kernel(const KgMmArgs a) {
         const int k0 = (kt0 + u) * MM_BK;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const bool ok = u < KT && k0 + src_k[g] < k_end && src[g] != 0xFFFFFFFFu;
+            const bool ok = u < KT && k0 + (is_b ? b_k[g] : a_k[g]) < k_end && src[g] != 0xFFFFFFFFu;
             const unsigned adv = (BMODE == 1 && is_b) ? (unsigned)((k0 >> 5) * 1024) : (unsigned)(k0 * 2);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + (8 * g + wave) * 1024), 16,
                                                      ok ? src[g] + adv : 0xFFFFFFFFu, 0, 0, 0);
@@ -359,7 +365,9 @@ __global__ void __launch_bounds__(512) kg_mm8_kernel(const KgMmArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fb[j][ks] = *(const kg_u4*)(half + mm_lds_off(wc * 32 + 16 * j + fr, 4 * ks + fg));
+            for (int ks = 0; ks < 2; ++ks)
+                fb[j][ks] = BMODE == 1 ? *(const kg_u4*)(half + ((wc * 2 + j) * 2 + ks) * 1024 + lane * 16)
+                                       : *(const kg_u4*)(half + mm_lds_off(wc * 32 + 16 * j + fr, 4 * ks + fg));
     };
     auto cluster = [&](auto mh_c, auto nh_c, const kg_u4 (&fb)[2][2]) {
         constexpr int MH = decltype(mh_c)::value, NH = decltype(nh_c)::value;
@@ -425,7 +433,150 @@ __global__ void __launch_bounds__(512) kg_mm8_kernel(const KgMmArgs a) {
     mm_epilogue<DT, BM, BN, WM, WN, OUT_F32>(a, acc, smem, m0, n0, zo, zi, wave, lane);
 }
 
+// The same construction for a 128 x 256 tile (products with too few rows to fill the chip with 256 x 256 tiles: the prompt
+// pass).  A wave computes 64 x 64; a K step is three half tiles (A, B_0, B_1) and two phases of 16 MFMAs (all four row
+// tiles x the first / second 32 columns); three LDS buffers of 48 KB, so a half tile is requested four phases before it
+// is read: phase 0 of step t requests A and B_0 of step t + 2, phase 1 its B_1, into the buffer step t - 1 was read from
+// two phases earlier.  Outstanding after the request, at most: phase 0 five half tiles (B_1 of this step has landed),
+// phase 1 four (A and B_0 of the next step have landed).
+template <int DT, int BMODE, bool OUT_F32>
+__global__ void __launch_bounds__(512) kg_mm8h_kernel(const KgMmArgs a) {
+    static_assert(BMODE == 0 || BMODE == 1, "row-major or packed B");
+    typedef KgT<DT> T;
+    constexpr int BM = 128, BN = 256, WM = 2, WN = 4;
+    constexpr int HALF = 128 * 128, BUF = 3 * HALF;
+    constexpr int OFF_A = 0, OFF_B0 = HALF, OFF_B1 = 2 * HALF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    int m0, n0;
+    mm_block_tile<BM, BN>(a, m0, n0);
+    if (a.causal == 1 && n0 > m0 + BM - 1) return;
+    const int zo = (int)blockIdx.z / a.batch_inner, zi = (int)blockIdx.z - zo * a.batch_inner;
+    const unsigned short* Ab = (const unsigned short*)a.A + (size_t)zo * a.sA + (size_t)zi * a.sA2;
+    const unsigned short* Bb = (const unsigned short*)a.B + (size_t)zo * a.sB + (size_t)(zi / a.b_inner_div) * a.sB2;
+    const size_t a_bytes = ((size_t)(a.M - 1) * a.lda + a.K) * 2;
+    const size_t b_bytes = BMODE == 1 ? (size_t)((a.N + 15) / 16) * (a.K / 32) * 1024 : ((size_t)(a.N - 1) * a.ldb + a.K) * 2;
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)(a_bytes > 0x7fffffffu ? 0x7fffffffu : a_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)(b_bytes > 0x7fffffffu ? 0x7fffffffu : b_bytes), 0x00020000);
+    const int k_end = (a.causal == 2) ? min(a.K, m0 + BM) : a.K;
+    const int kt0 = (a.causal == 3) ? m0 / MM_BK : 0;
+    const int KT = (k_end + MM_BK - 1) / MM_BK - kt0;
+
+    unsigned a_src[2], b_src[2][2];         // [g], [half][g]
+    int a_k[2], b_k[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int q = (8 * g + wave) * 8 + (lane >> 3), ch = (lane & 7) ^ ((q >> 1) & 7);
+        a_k[g] = 8 * ch; b_k[g] = BMODE == 1 ? 32 * (wave & 1) + 8 * (lane >> 4) : 8 * ch;
+        a_src[g] = m0 + q < a.M ? (unsigned)(((size_t)(m0 + q) * a.lda + 8 * ch) * 2) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (BMODE == 1) {
+                // packed B: the half tile's LDS image is the 16 packed tiles themselves (8 row groups x 2 k tiles of 1 KiB), load g of
+                // wave w copies tile 8 g + w whole: 1 KiB of consecutive memory, and a fragment read is 1 KiB of consecutive LDS
+                const int idx = 8 * g + wave, rgl = idx >> 1, n = n0 + (rgl >> 1) * 64 + h * 32 + (rgl & 1) * 16;
+                b_src[h][g] = n < a.N ? (unsigned)((((size_t)(n >> 4) * (a.K >> 5) + (idx & 1)) * 512 + lane * 8) * 2) : 0xFFFFFFFFu;
+            } else {
+                const int n = n0 + (q >> 5) * 64 + h * 32 + (q & 31);
+                b_src[h][g] = n < a.N ? (unsigned)(((size_t)n * a.ldb + 8 * ch) * 2) : 0xFFFFFFFFu;
+            }
+        }
+    }
+    auto request = [&](char* dst, const unsigned (&src)[2], const __amdgpu_buffer_rsrc_t& rs, bool is_b, int u) {
+        const int k0 = (kt0 + u) * MM_BK;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const bool ok = u < KT && k0 + (is_b ? b_k[g] : a_k[g]) < k_end && src[g] != 0xFFFFFFFFu;
+            const unsigned adv = (BMODE == 1 && is_b) ? (unsigned)((k0 >> 5) * 1024) : (unsigned)(k0 * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + (8 * g + wave) * 1024), 16,
+                                                     ok ? src[g] + adv : 0xFFFFFFFFu, 0, 0, 0);
+        }
+    };
+
+    kg_f4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = kg_f4{0.f, 0.f, 0.f, 0.f};
+    kg_u4 fa[4][2], fb0[2][2], fb1[2][2];
+
+    auto read_a = [&](const char* half) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = *(const kg_u4*)(half + mm_lds_off(wr * 64 + 16 * i + fr, 4 * ks + fg));
+    };
+    auto read_b = [&](const char* half, kg_u4 (&fb)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                fb[j][ks] = BMODE == 1 ? *(const kg_u4*)(half + ((wc * 2 + j) * 2 + ks) * 1024 + lane * 16)
+                                       : *(const kg_u4*)(half + mm_lds_off(wc * 32 + 16 * j + fr, 4 * ks + fg));
+    };
+    auto cluster = [&](auto nh_c, const kg_u4 (&fb)[2][2]) {
+        constexpr int NH = decltype(nh_c)::value;
+        MM8_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][2 * NH + j] = T::mfma(fb[j][ks], fa[i][ks], acc[i][2 * NH + j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    auto step = [&](auto b_c, int t) {
+        constexpr int B = decltype(b_c)::value;
+        char* cur = smem + B * BUF;
+        char* nx2 = smem + ((B + 2) % 3) * BUF;
+        // phase 0
+        read_b(cur + OFF_B0, fb0); __builtin_amdgcn_sched_barrier(0); read_a(cur + OFF_A);
+        request(nx2 + OFF_A, a_src, ar, false, t + 2);
+        request(nx2 + OFF_B0, b_src[0], br, true, t + 2);
+        MM8_WAIT_VM(10); __builtin_amdgcn_s_barrier();
+        cluster(I0(), fb0);
+        __builtin_amdgcn_s_barrier();
+        // phase 1
+        read_b(cur + OFF_B1, fb1);
+        request(nx2 + OFF_B1, b_src[1], br, true, t + 2);
+        MM8_WAIT_VM(8); __builtin_amdgcn_s_barrier();
+        cluster(I1(), fb1);
+        __builtin_amdgcn_s_barrier();
+    };
+
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        request(smem + u * BUF + OFF_A, a_src, ar, false, u);
+        request(smem + u * BUF + OFF_B0, b_src[0], br, true, u);
+        request(smem + u * BUF + OFF_B1, b_src[1], br, true, u);
+    }
+    MM8_WAIT_VM(8); __builtin_amdgcn_s_barrier();        // A and B_0 of step 0 are in LDS, every wave's share
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    int t = 0;
+    for (; t + 2 < KT; t += 3) { step(I0(), t); step(I1(), t + 1); step(I2(), t + 2); }
+    if (t < KT) {
+        step(I0(), t);
+        if (t + 1 < KT) step(I1(), t + 1);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    MM8_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    mm_epilogue<DT, BM, BN, WM, WN, OUT_F32>(a, acc, smem, m0, n0, zo, zi, wave, lane);
+}
+
 static int g_mm_ncu = 256;
+// flop rate of a CU busy with one 256 x 256 direct-to-LDS tile / one 128 x 256 tile, in the units of mm_launch's model
+#define MM_RATE_BIG8 1.75
+#define MM_RATE_HALF 1.4
 template <int DT, int BM, int BN, int WM, int WN, int BMODE>
 static void mm_launch_tile(const KgMmArgs& a, hipStream_t st) {
     const size_t smem = 2 * (size_t)(BM + BN) * MM_BK * 2;
@@ -441,13 +592,25 @@ static void mm_launch(const KgMmArgs& a, hipStream_t st) {
     // 8192 x 4096 x 4096 is 296 us against 410 us (model 0.71), 640 x 22016 x 4096 232 against 167 us.
     const double t_big = (double)(((long)((a.M + 255) / 256) * ((a.N + 255) / 256) * a.batch + g_mm_ncu - 1) / g_mm_ncu) * (65536.0 / 1.4);
     const double t_small = (double)(((long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch + 2 * g_mm_ncu - 1) / (2 * g_mm_ncu)) * (16384.0 / 0.5);
-    const bool big = a.tile >= 2 || (a.tile == 0 && t_big < t_small);
-    if (big && a.tile != 2 && BMODE != 2) {               // the large tile's direct-to-LDS form (a.tile == 2 asks for the register-staged one)
+    const double t_half = (double)(((long)((a.M + 127) / 128) * ((a.N + 255) / 256) * a.batch + g_mm_ncu - 1) / g_mm_ncu) * (32768.0 / MM_RATE_HALF);
+    int pick = a.tile;                                    // 1: 128 x 128; 2 / 3: 256 x 256 staged through registers / loads write LDS; 4: 128 x 256
+    if (pick == 0) {
+        const double t_b = BMODE == 2 ? t_big : t_big * (1.4 / MM_RATE_BIG8);
+        pick = (t_b <= t_small && (BMODE == 2 || t_b <= t_half)) ? 3 : ((BMODE != 2 && t_half < t_small) ? 4 : 1);
+    }
+    if (BMODE == 2 && pick >= 3) pick = pick == 3 ? 2 : 1;   // a K-major B has no direct-to-LDS form (the image is not lane-linear)
+    if (pick >= 3) {
         constexpr int BM8 = BMODE == 2 ? 0 : BMODE;
-        const dim3 grid(((a.M + 255) / 256) * ((a.N + 255) / 256), 1, a.batch), block(512);
-        if (a.out_f32) hipLaunchKernelGGL((kg_mm8_kernel<DT, BM8, true>), grid, block, 131072, st, a);
-        else hipLaunchKernelGGL((kg_mm8_kernel<DT, BM8, false>), grid, block, 131072, st, a);
-    } else if (big) mm_launch_tile<DT, 256, 256, 2, 4, BMODE>(a, st);
+        const int bm = pick == 3 ? 256 : 128;
+        const dim3 grid(((a.M + bm - 1) / bm) * ((a.N + 255) / 256), 1, a.batch), block(512);
+        if (pick == 3) {
+            if (a.out_f32) hipLaunchKernelGGL((kg_mm8_kernel<DT, BM8, true>), grid, block, 131072, st, a);
+            else hipLaunchKernelGGL((kg_mm8_kernel<DT, BM8, false>), grid, block, 131072, st, a);
+        } else {
+            if (a.out_f32) hipLaunchKernelGGL((kg_mm8h_kernel<DT, BM8, true>), grid, block, 147456, st, a);
+            else hipLaunchKernelGGL((kg_mm8h_kernel<DT, BM8, false>), grid, block, 147456, st, a);
+        }
+    } else if (pick == 2) mm_launch_tile<DT, 256, 256, 2, 4, BMODE>(a, st);
     else mm_launch_tile<DT, 128, 128, 2, 2, BMODE>(a, st);
 }
 
@@ -459,7 +622,7 @@ int kg_launch_mm(const KgMmArgs& a, int dtype, hipStream_t st) {
     if (a.b_packed == 2 && (a.N & 7)) return -1;
     if (a.causal < 0 || a.causal > 4 || (a.causal == 4 && a.b_packed != 2)) return -1;
     if (a.batch_inner < 1 || a.batch % a.batch_inner || a.b_inner_div < 1 || (a.sA2 & 7) || (a.sB2 & 7)) return -1;
-    if (a.tile < 0 || a.tile > 3) return -1;
+    if (a.tile < 0 || a.tile > 4) return -1;
     if (a.epi < 0 || a.epi > 2 || (a.epi && (a.out_f32 || a.batch != 1)) || (a.epi == MM_EPI_RESID && !a.resid) || (a.epi == MM_EPI_SILU_MUL && (a.N & 1))) return -1;
     if (dtype == KG_F16) { if (a.b_packed == 1) mm_launch<KG_F16, 1>(a, st); else if (a.b_packed == 2) mm_launch<KG_F16, 2>(a, st); else mm_launch<KG_F16, 0>(a, st); }
     else { if (a.b_packed == 1) mm_launch<KG_BF16, 1>(a, st); else if (a.b_packed == 2) mm_launch<KG_BF16, 2>(a, st); else mm_launch<KG_BF16, 0>(a, st); }
@@ -470,6 +633,7 @@ template <int DT, int P, bool F> static void mm_attr() {
     (void)hipFuncSetAttribute((const void*)kg_mm_kernel<DT, 128, 128, 2, 2, P, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * MM_BK * 2);
     (void)hipFuncSetAttribute((const void*)kg_mm_kernel<DT, 256, 256, 2, 4, P, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * MM_BK * 2);
     if (P != 2) (void)hipFuncSetAttribute((const void*)kg_mm8_kernel<DT, (P == 2 ? 0 : P), F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    if (P != 2) (void)hipFuncSetAttribute((const void*)kg_mm8h_kernel<DT, (P == 2 ? 0 : P), F>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
 }
 void kg_mm_init() {
     int dev = 0, ncu = 0;

@@ -34,14 +34,14 @@ def mm(A, B, out_f32=False, layout=0, causal=0, alpha=1.0, N=None, ldb=None):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 def test_products_against_fp32(dtype, tile, monkeypatch):
-    # 1 / 2 / 3: every shape through the 128 x 128 tile / the 256 x 256 tile staged through registers / the 256 x 256 tile
-    # whose loads write LDS directly (K-major B: the register-staged one)
+    # 1 / 2 / 3 / 4: every shape through the 128 x 128 tile / the 256 x 256 tile staged through registers / the 256 x 256
+    # and the 128 x 256 tile whose loads write LDS directly (K-major B: the register-staged ones)
     monkeypatch.setenv("KG_MM_TILE", str(tile))
     g = torch.Generator(device=DEV).manual_seed(tile)
     out_tol = 2e-3 if dtype == torch.float16 else 1.2e-2
-    for (M, N, K) in ((128, 128, 64), (200, 136, 72), (1000, 520, 4096), (77, 4096, 256), (257, 129, 8), (513, 700, 1032), (300, 260, 192), (256, 512, 128)):
+    for (M, N, K) in ((128, 128, 64), (200, 136, 72), (1000, 520, 4096), (77, 4096, 256), (257, 129, 8), (513, 700, 1032), (300, 260, 192), (256, 512, 128), (130, 300, 320), (128, 256, 448)):
         A = torch.randn(M, K, device=DEV, generator=g).to(dtype); B = torch.randn(N, K, device=DEV, generator=g).to(dtype)
         ref = A.float() @ B.float().T
         assert float((mm(A, B, out_f32=True) - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-4
@@ -60,7 +60,7 @@ def test_products_against_fp32(dtype, tile, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("tile", [0, 3])
+@pytest.mark.parametrize("tile", [0, 3, 4])
 def test_causal_and_head_strided_products(dtype, tile, monkeypatch):
     monkeypatch.setenv("KG_MM_TILE", str(tile))
     lib = _lib.lib()
