@@ -75,6 +75,8 @@ struct kg_session {
     // prompt pass that runs layer by layer over the whole prompt (t_max rows each): hidden rows, normalised rows, stored
     // q/k/v rows, q in head order, attention output, MLP activations
     char *pm_h, *pm_xn, *pm_qkv, *pm_q, *pm_ao, *pm_act;
+    float* pm_part;                     // fp32 partial products of the projections whose K is cut into ranges: 2 * t_max rows of d
+    int rows_ksplit;                    // tuning: 0 chosen by size, 1 never, n > 1 always n ranges (as far as the buffer allows)
     int rows_prefill_min;              // prompts of at least this many tokens take that pass (0: never)
     int gemm_prefill;                  // 1: prompts go through the 128-row GEMM passes
     int vanilla_gemv;                  // 1: plain decoding runs every layer and the head through the 1-row GEMV kernels
@@ -162,8 +164,9 @@ static void carve(kg_session* s, Carver& c, const kg_shape* sh, int t_max) {
     char* pm_q = c.take<char>(TR * qd * e);
     char* pm_ao = c.take<char>(TR * qd * e);
     char* pm_act = c.take<char>(TR * F * e);
+    float* pm_part = c.take<float>(2 * TR * d);
     if (s) {
-        s->pm_h = pm_h; s->pm_xn = pm_xn; s->pm_qkv = pm_qkv; s->pm_q = pm_q; s->pm_ao = pm_ao; s->pm_act = pm_act;
+        s->pm_h = pm_h; s->pm_xn = pm_xn; s->pm_qkv = pm_qkv; s->pm_q = pm_q; s->pm_ao = pm_ao; s->pm_act = pm_act; s->pm_part = pm_part;
         s->prog_dev[0] = prog0; s->prog_dev[1] = prog1; s->prog_dev[2] = prog2; s->prog_cap = prog_cap; s->bar = bar; s->rot = rot; s->rot_layer = rot_layer;
         s->pf_h = pf_h; s->pf_xn = pf_xn; s->pf_xq = pf_xq; s->pf_ao = pf_ao; s->pf_act = pf_act; s->pf_part = pf_part;
         s->state = state; s->tokens = tokens;
@@ -221,7 +224,7 @@ extern "C" int kg_session_create(const kg_shape* shape, const kg_weights* weight
     s->gemm_prefill = s->v_transposed;           // the GEMM passes need the MFMA attention kernel
     // From 192 prompt tokens on the prompt goes through the layers one whole-prompt pass at a time (measured at the 7B
     // shape: 640 tokens 25.5 ms in 128-row passes); shorter prompts fill too few tiles of the large matrix products.
-    s->rows_prefill_min = (s->v_transposed && shape->hidden_size % 8 == 0 && shape->intermediate_size % 8 == 0) ? 192 : 0;
+    s->rows_prefill_min = (s->v_transposed && shape->hidden_size % 8 == 0 && shape->intermediate_size % 8 == 0) ? 129 : 0;
     s->bench_layers = s->sh.num_layers;
     s->vanilla_gemv = 0;
     s->attn_teams = 1;
@@ -274,6 +277,7 @@ extern "C" int kg_session_set(kg_session* s, const char* key, int value) {
     if (k == "attn_nsplit") { if (value > 32) return fail(-1, "nsplit <= 32"); s->attn_nsplit = value; done = true; }
     if (k == "gemm_prefill") { s->gemm_prefill = (value >= 2 && s->v_transposed) ? 1 : 0; done = true; }   // 1: off, 2: on
     if (k == "rows_prefill_min") { s->rows_prefill_min = (value >= 2 && s->v_transposed) ? value : 0; done = true; }   // 1: off
+    if (k == "rows_ksplit") { if (value > 17) return fail(-1, "rows_ksplit <= 17"); s->rows_ksplit = value - 1; done = true; }   // 1: by size, 2: never, n + 1: n ranges
     if (k == "vanilla_gemv") { s->vanilla_gemv = value >= 2 ? 1 : 0; done = true; }   // 1: off, 2: on
     if (k == "bench_layers") { s->bench_layers = value < s->sh.num_layers ? value : s->sh.num_layers; done = true; }
     if (k == "accept_top_k") { if (value > s->sh.vocab_size) return fail(-1, "accept_top_k <= vocab_size"); s->accept_top_k = value; done = true; }
@@ -348,6 +352,7 @@ extern "C" int kg_session_get(kg_session* s, const char* key) {
     if (k == "accept_typical") return s->accept_typical;
     if (k == "gemm_prefill") return s->gemm_prefill;
     if (k == "rows_prefill_min") return s->rows_prefill_min;
+    if (k == "rows_ksplit") return s->rows_ksplit + 1;
     if (k == "vanilla_gemv") return s->vanilla_gemv;
     if (k == "persist") return s->persist;
     if (k == "prefill_rows") return s->prefill_rows;
@@ -1051,14 +1056,48 @@ static int run_layer_rows(kg_session* s, const kg_layer_weights& lw, void* kc, v
         a.b_packed = 1; a.alpha = 1.0f; a.epi = epi; a.resid = resid; a.ldr = d;
         return kg_launch_mm(a, dt, st);
     };
+    // The d-column projections (o, down) have 16 column tiles at d = 4096: a short prompt leaves most CUs without a tile.
+    // Their K is then cut into ranges (grid.y) that write fp32 partial products; the kernel that adds the ranges also adds
+    // the residual and, after o, normalises the finished rows for gate/up (it replaces that norm kernel).
+    // Cost of n ranges in steps of 64 k: rounds of blocks x steps per range, plus what the adding kernel reads.
+    auto ranges = [&](int K) -> int {
+        if (s->rows_ksplit == 1) return 1;
+        const int tiles = ((rows + 127) / 128) * ((d + 255) / 256), steps = (K + 63) / 64, cap = (int)(2 * (size_t)s->buf.t_max / (size_t)rows);
+        if (s->rows_ksplit > 1) return std::max(1, std::min(std::min(s->rows_ksplit, cap), steps));
+        int best = 1; double best_c = 1e30;
+        for (int n = 1; n <= 16 && n <= cap && n <= steps; ++n) {
+            const double c = (double)((tiles * n + g_ncu - 1) / g_ncu) * ((steps + n - 1) / n) + (n > 1 ? 5.0 + 3.3 * n * ((double)rows * d / 2.6e6) : 0.0);
+            if (c < best_c) { best_c = c; best = n; }
+        }
+        return best;
+    };
+    auto mm_ranges = [&](const void* A, int K, const void* Wp, int n) -> int {
+        KgMmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.A = A; a.B = Wp; a.C = s->pm_part; a.M = rows; a.N = d; a.K = K; a.lda = K; a.ldc = d; a.batch = 1; a.batch_inner = 1; a.b_inner_div = 1;
+        a.b_packed = 1; a.alpha = 1.0f; a.out_f32 = 1; a.ksplit = n; a.sCk = (long long)rows * d; a.tile = 4;
+        return kg_launch_mm(a, dt, st);
+    };
     KG_TRY(kg_launch_rows_rmsnorm(h_in, d, lw.norm1, sh.rms_eps, d, s->pm_xn, d, rows, dt, st));
     KG_TRY(mm(s->pm_xn, d, lw.wqkv, nqkv, s->pm_qkv, nqkv, MM_EPI_STORE, nullptr));
     KG_TRY(kg_launch_rows_rope_kv(s->pm_qkv, rows, 0, sh.head_dim, s->q_dim, s->kv_dim, s->w.rope_cos, s->w.rope_sin, s->pm_q, kc, vc, s->buf.t_max, s->v_transposed, dt, st));
     KG_TRY(kg_launch_attn_rows(s->pm_q, kc, vc, s->pm_ao, rows, 0, sh.num_heads, sh.num_kv_heads, sh.head_dim, s->buf.t_max, dt, st));
-    KG_TRY(mm(s->pm_ao, s->q_dim, lw.wo, d, h_out, d, MM_EPI_RESID, h_in));
-    if (lw.wgu == nullptr) return 0;
-    KG_TRY(kg_launch_rows_rmsnorm(h_out, d, lw.norm2, sh.rms_eps, d, s->pm_xn, d, rows, dt, st));
+    const int n_o = ranges(s->q_dim);
+    if (n_o > 1) {
+        KG_TRY(mm_ranges(s->pm_ao, s->q_dim, lw.wo, n_o));
+        KG_TRY(kg_launch_rows_reduce(s->pm_part, n_o, (long long)rows * d, d, h_in, d, h_out, d, lw.wgu ? lw.norm2 : nullptr, sh.rms_eps, s->pm_xn, d, rows, dt, st));
+        if (lw.wgu == nullptr) return 0;
+    } else {
+        KG_TRY(mm(s->pm_ao, s->q_dim, lw.wo, d, h_out, d, MM_EPI_RESID, h_in));
+        if (lw.wgu == nullptr) return 0;
+        KG_TRY(kg_launch_rows_rmsnorm(h_out, d, lw.norm2, sh.rms_eps, d, s->pm_xn, d, rows, dt, st));
+    }
     KG_TRY(mm(s->pm_xn, d, lw.wgu, 2 * F, s->pm_act, F, MM_EPI_SILU_MUL, nullptr));
+    const int n_d = ranges(F);
+    if (n_d > 1) {
+        KG_TRY(mm_ranges(s->pm_act, F, lw.wdown, n_d));
+        return kg_launch_rows_reduce(s->pm_part, n_d, (long long)rows * d, d, h_out, d, h_out, d, nullptr, sh.rms_eps, nullptr, 0, rows, dt, st);
+    }
     return mm(s->pm_act, F, lw.wdown, d, h_out, d, MM_EPI_RESID, h_out);
 }
 

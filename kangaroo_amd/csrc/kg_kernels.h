@@ -137,15 +137,23 @@ struct KgMmArgs {
                                         // 3: A is upper triangular: K is walked from the tile's first row on;
                                         // 4: a K-major B whose row k ends at column k: K is walked from the tile's first column on
     float alpha;
-    int tile;                           // 0: chosen by size; measurements: 1: 128 x 128 tiles; 2: 256 x 256, staged through registers; 3: 256 x 256, loads write LDS
+    int tile;                           // 0: chosen by size; measurements: 1: 128 x 128 tiles; 2: 256 x 256, staged through registers;
+                                        //    3 / 4: 256 x 256 / 128 x 256, loads write LDS
     // 16-bit output only.  epi 1: C = round16(resid + round16(A.B^T)) (the residual add of a decoder layer, resid rows ldr
     // elements apart); epi 2: columns (2i, 2i+1) hold (gate_i, up_i) and C[m][i] = silu(gate) * up with the reference's
     // roundings (N / 2 output columns, ldc counts those)
     int epi; const void* resid; long long ldr;
+    // > 1: K cut into ksplit ranges of whole 64-steps (grid.y), range r writes its fp32 partial product at C + r * sCk elements;
+    // needs out_f32, no epilogue, no causal mode, batch 1, a row-major or packed B
+    int ksplit; long long sCk;
 };
 enum { MM_EPI_STORE = 0, MM_EPI_RESID = 1, MM_EPI_SILU_MUL = 2 };
 // rows of the prompt pass that runs layer by layer over the whole prompt (prefill.hip)
 int kg_launch_rows_rmsnorm(const void* x, int ld, const void* w, float eps, int K, void* out, int ld_out, int rows, int dtype, hipStream_t st);
+// h_out[m] = round16(resid[m] + round16(part[0][m] + part[1][m] + ...)) (ranges added in order); with w also xn[m] = the RMSNorm of
+// h_out[m] times w, as kg_launch_rows_rmsnorm computes it.  h_out may alias resid.
+int kg_launch_rows_reduce(const float* part, int ksplit, long long split_stride, int N, const void* resid, int ldr, void* h_out, int ldh,
+                          const void* w, float eps, void* xn, int ldx, int rows, int dtype, hipStream_t st);
 int kg_launch_rows_rope_kv(const void* qkv, int rows, int pos0, int head_dim, int q_dim, int kv_dim, const float* rope_cos, const float* rope_sin,
                            void* q_out, void* k_cache, void* v_cache, int t_max, int v_transposed, int dtype, hipStream_t st);
 int kg_launch_rows_embed(const int* tokens, int pos0, int rows, const void* embed, int d, void* out, hipStream_t st);

@@ -63,11 +63,11 @@ __device__ __forceinline__ void mm_block_tile(const KgMmArgs& a, int& m0, int& n
 // Every wave of the block must be past its last LDS read of the pipeline, and no write to LDS may be in flight.
 template <int DT, int BM, int BN, int WM, int WN, bool OUT_F32>
 __device__ __forceinline__ void mm_epilogue(const KgMmArgs& a, kg_f4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int m0, int n0, int zo, int zi,
-                                            int wave, int lane) {
+                                            int wave, int lane, size_t c_off = 0) {
     typedef KgT<DT> T;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     const int wr = wave / WN, wc = wave % WN, fr = lane & 15, fg = lane >> 4;
-    const size_t cb = (size_t)zo * a.sC + (size_t)zi * a.sC2;
+    const size_t cb = (size_t)zo * a.sC + (size_t)zi * a.sC2 + c_off;
     constexpr int WROWS = BM / WM, WCOLS = BN / WN;              // the wave's part of the tile
     constexpr int ESZ = OUT_F32 ? 4 : 2;
     constexpr int ROWB = WCOLS * ESZ + 16;                       // padded row of the staging image (keeps 16-byte alignment, staggers banks)
@@ -310,8 +310,11 @@ __global__ void __launch_bounds__(512) kg_mm8_kernel(const KgMmArgs a) {
     const size_t b_bytes = BMODE == 1 ? (size_t)((a.N + 15) / 16) * (a.K / 32) * 1024 : ((size_t)(a.N - 1) * a.ldb + a.K) * 2;
     const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)(a_bytes > 0x7fffffffu ? 0x7fffffffu : a_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)(b_bytes > 0x7fffffffu ? 0x7fffffffu : b_bytes), 0x00020000);
-    const int k_end = (a.causal == 2) ? min(a.K, m0 + BM) : a.K;
-    const int kt0 = (a.causal == 3) ? m0 / MM_BK : 0;
+    // a K range of whole steps per grid.y (ksplit > 1: no causal mode)
+    const int k_per = a.ksplit > 1 ? ((a.K + MM_BK - 1) / MM_BK + a.ksplit - 1) / a.ksplit * MM_BK : a.K;
+    const int k_lo = a.ksplit > 1 ? (int)blockIdx.y * k_per : 0;
+    const int k_end = a.ksplit > 1 ? min(a.K, k_lo + k_per) : ((a.causal == 2) ? min(a.K, m0 + BM) : a.K);
+    const int kt0 = a.ksplit > 1 ? k_lo / MM_BK : ((a.causal == 3) ? m0 / MM_BK : 0);
     const int KT = (k_end + MM_BK - 1) / MM_BK - kt0;
 
     // ---- sources: load g (0, 1) of a half tile fills LDS rows 8 (8 g + wave) .. + 7, lane l row l >> 3, 16-byte slot l & 7 ----
@@ -430,7 +433,7 @@ __global__ void __launch_bounds__(512) kg_mm8_kernel(const KgMmArgs a) {
     if (wr == 0) __builtin_amdgcn_s_barrier();
     MM8_WAIT_VM(0);                                       // the requests past the last step
     __builtin_amdgcn_s_barrier();
-    mm_epilogue<DT, BM, BN, WM, WN, OUT_F32>(a, acc, smem, m0, n0, zo, zi, wave, lane);
+    mm_epilogue<DT, BM, BN, WM, WN, OUT_F32>(a, acc, smem, m0, n0, zo, zi, wave, lane, a.ksplit > 1 ? (size_t)blockIdx.y * (size_t)a.sCk : 0);
 }
 
 // The same construction for a 128 x 256 tile (products with too few rows to fill the chip with 256 x 256 tiles: the prompt
@@ -461,8 +464,11 @@ __global__ void __launch_bounds__(512) kg_mm8h_kernel(const KgMmArgs a) {
     const size_t b_bytes = BMODE == 1 ? (size_t)((a.N + 15) / 16) * (a.K / 32) * 1024 : ((size_t)(a.N - 1) * a.ldb + a.K) * 2;
     const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)(a_bytes > 0x7fffffffu ? 0x7fffffffu : a_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)(b_bytes > 0x7fffffffu ? 0x7fffffffu : b_bytes), 0x00020000);
-    const int k_end = (a.causal == 2) ? min(a.K, m0 + BM) : a.K;
-    const int kt0 = (a.causal == 3) ? m0 / MM_BK : 0;
+    // a K range of whole steps per grid.y (ksplit > 1: no causal mode)
+    const int k_per = a.ksplit > 1 ? ((a.K + MM_BK - 1) / MM_BK + a.ksplit - 1) / a.ksplit * MM_BK : a.K;
+    const int k_lo = a.ksplit > 1 ? (int)blockIdx.y * k_per : 0;
+    const int k_end = a.ksplit > 1 ? min(a.K, k_lo + k_per) : ((a.causal == 2) ? min(a.K, m0 + BM) : a.K);
+    const int kt0 = a.ksplit > 1 ? k_lo / MM_BK : ((a.causal == 3) ? m0 / MM_BK : 0);
     const int KT = (k_end + MM_BK - 1) / MM_BK - kt0;
 
     unsigned a_src[2], b_src[2][2];         // [g], [half][g]
@@ -570,7 +576,7 @@ __global__ void __launch_bounds__(512) kg_mm8h_kernel(const KgMmArgs a) {
     if (wr == 0) __builtin_amdgcn_s_barrier();
     MM8_WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
-    mm_epilogue<DT, BM, BN, WM, WN, OUT_F32>(a, acc, smem, m0, n0, zo, zi, wave, lane);
+    mm_epilogue<DT, BM, BN, WM, WN, OUT_F32>(a, acc, smem, m0, n0, zo, zi, wave, lane, a.ksplit > 1 ? (size_t)blockIdx.y * (size_t)a.sCk : 0);
 }
 
 static int g_mm_ncu = 256;
@@ -598,11 +604,12 @@ static void mm_launch(const KgMmArgs& a, hipStream_t st) {
         const double t_b = BMODE == 2 ? t_big : t_big * (1.4 / MM_RATE_BIG8);
         pick = (t_b <= t_small && (BMODE == 2 || t_b <= t_half)) ? 3 : ((BMODE != 2 && t_half < t_small) ? 4 : 1);
     }
+    if (a.ksplit > 1 && pick < 3) pick = 4;
     if (BMODE == 2 && pick >= 3) pick = pick == 3 ? 2 : 1;   // a K-major B has no direct-to-LDS form (the image is not lane-linear)
     if (pick >= 3) {
         constexpr int BM8 = BMODE == 2 ? 0 : BMODE;
         const int bm = pick == 3 ? 256 : 128;
-        const dim3 grid(((a.M + bm - 1) / bm) * ((a.N + 255) / 256), 1, a.batch), block(512);
+        const dim3 grid(((a.M + bm - 1) / bm) * ((a.N + 255) / 256), a.ksplit > 1 ? a.ksplit : 1, a.batch), block(512);
         if (pick == 3) {
             if (a.out_f32) hipLaunchKernelGGL((kg_mm8_kernel<DT, BM8, true>), grid, block, 131072, st, a);
             else hipLaunchKernelGGL((kg_mm8_kernel<DT, BM8, false>), grid, block, 131072, st, a);
@@ -623,6 +630,7 @@ int kg_launch_mm(const KgMmArgs& a, int dtype, hipStream_t st) {
     if (a.causal < 0 || a.causal > 4 || (a.causal == 4 && a.b_packed != 2)) return -1;
     if (a.batch_inner < 1 || a.batch % a.batch_inner || a.b_inner_div < 1 || (a.sA2 & 7) || (a.sB2 & 7)) return -1;
     if (a.tile < 0 || a.tile > 4) return -1;
+    if (a.ksplit < 0 || a.ksplit > 64 || (a.ksplit > 1 && (!a.out_f32 || a.epi || a.causal || a.batch != 1 || a.b_packed == 2 || a.tile == 1 || a.tile == 2 || a.sCk < (long long)a.M * a.ldc))) return -1;
     if (a.epi < 0 || a.epi > 2 || (a.epi && (a.out_f32 || a.batch != 1)) || (a.epi == MM_EPI_RESID && !a.resid) || (a.epi == MM_EPI_SILU_MUL && (a.N & 1))) return -1;
     if (dtype == KG_F16) { if (a.b_packed == 1) mm_launch<KG_F16, 1>(a, st); else if (a.b_packed == 2) mm_launch<KG_F16, 2>(a, st); else mm_launch<KG_F16, 0>(a, st); }
     else { if (a.b_packed == 1) mm_launch<KG_BF16, 1>(a, st); else if (a.b_packed == 2) mm_launch<KG_BF16, 2>(a, st); else mm_launch<KG_BF16, 0>(a, st); }

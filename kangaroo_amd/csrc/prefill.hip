@@ -52,6 +52,61 @@ int kg_launch_rows_rmsnorm(const void* x, int ld, const void* w, float eps, int 
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// The end of a projection whose K was cut into ranges (csrc/mm.hip, ksplit): the ranges' fp32 partial sums are added in range
+// order, rounded to 16 bits as the stored product would have been, added to the residual row and rounded again; with a
+// weight vector the finished row is also normalised for the next projection (same arithmetic as kg_rows_rmsnorm_kernel on
+// the stored row).  One block per row; a thread owns the 16-byte pieces t, t + 256, ...
+template <int DT>
+__global__ void __launch_bounds__(256) kg_rows_reduce_kernel(const float* part, int ksplit, size_t split_stride, int N, const unsigned short* resid, int ldr,
+                                                             unsigned short* h_out, int ldh, const unsigned short* w, float eps, unsigned short* xn, int ldx) {
+    typedef KgT<DT> T;
+    __shared__ float red[4];
+    const size_t m = blockIdx.x;
+    const float* pr = part + m * (size_t)N;
+    const unsigned short* rr = resid + m * ldr;
+    unsigned short* hr = h_out + m * ldh;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < (N >> 3); i += 256) {
+        kg_f4 lo = ((const kg_f4*)pr)[2 * i], hi = ((const kg_f4*)pr)[2 * i + 1];
+        for (int r = 1; r < ksplit; ++r) {
+            const kg_f4* q = (const kg_f4*)(pr + (size_t)r * split_stride);
+            lo = lo + q[2 * i]; hi = hi + q[2 * i + 1];
+        }
+        const kg_us8 rs = __builtin_bit_cast(kg_us8, ((const kg_u4*)rr)[i]);
+        kg_us8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = kg_round<DT>(T::to_f(rs[e]) + kg_round<DT>(e < 4 ? lo[e] : hi[e - 4]));
+            o[e] = T::from_f(f); ss += f * f;
+        }
+        ((kg_u4*)hr)[i] = __builtin_bit_cast(kg_u4, o);
+    }
+    if (w == nullptr) return;
+    ss = kg_wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
+    const float rstd = rsqrtf(ss / (float)N + eps);
+    unsigned short* orow = xn + m * ldx;
+    for (int i = threadIdx.x; i < (N >> 3); i += 256) {
+        const kg_us8 h = __builtin_bit_cast(kg_us8, ((const kg_u4*)hr)[i]);          // this thread's own stores
+        const kg_us8 g = __builtin_bit_cast(kg_us8, ((const kg_u4*)w)[i]);
+        kg_us8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = T::from_f(T::to_f(g[e]) * kg_round<DT>(T::to_f(h[e]) * rstd));
+        ((kg_u4*)orow)[i] = __builtin_bit_cast(kg_u4, o);
+    }
+}
+int kg_launch_rows_reduce(const float* part, int ksplit, long long split_stride, int N, const void* resid, int ldr, void* h_out, int ldh,
+                          const void* w, float eps, void* xn, int ldx, int rows, int dtype, hipStream_t st) {
+    if (!part || !resid || !h_out || ksplit < 1 || rows < 1 || (N & 7) || (ldr & 7) || (ldh & 7) || (split_stride & 3) || (w && (!xn || (ldx & 7)))) return -1;
+    if (dtype == KG_F16) hipLaunchKernelGGL(kg_rows_reduce_kernel<KG_F16>, dim3(rows), dim3(256), 0, st, part, ksplit, (size_t)split_stride, N, (const unsigned short*)resid, ldr,
+                                            (unsigned short*)h_out, ldh, (const unsigned short*)w, eps, (unsigned short*)xn, ldx);
+    else hipLaunchKernelGGL(kg_rows_reduce_kernel<KG_BF16>, dim3(rows), dim3(256), 0, st, part, ksplit, (size_t)split_stride, N, (const unsigned short*)resid, ldr,
+                            (unsigned short*)h_out, ldh, (const unsigned short*)w, eps, (unsigned short*)xn, ldx);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // RoPE + cache append on the stored rows of the fused q/k/v product (kangaroo/adapter.py:80-95,181-189).  qkv[m] holds the
 // packed row order of wqkv: [q heads | k heads | v heads], inside a head the pairs (j, j + hd/2) adjacent as (2j, 2j + 1).
 // q goes to q_out[m] in the original order, K to cache slot pos0 + m, V likewise (transposed layout: [Hkv][hd][t_max]).

@@ -29,7 +29,8 @@ for op in (() if "--short" in sys.argv else ("qkv", "o", "gateup", "down", "head
 short = "--short" in sys.argv        # one prompt, few tokens, no per-kernel loop: for counter passes
 if "--prefill" in sys.argv:
     g = torch.Generator().manual_seed(2)
-    for plen in (128, 640, 1500):
+    plens = tuple(int(x) for x in sys.argv[sys.argv.index("--plens") + 1].split(",")) if "--plens" in sys.argv else (128, 640, 1500)
+    for plen in plens:
         ids = torch.randint(3, shape.vocab_size, (plen,), generator=g)
         eng.generate(ids, 2, mode="kangaroo")
         ms = [eng.generate(ids, 2, mode="kangaroo")[1].prefill_ms for _ in range(3)]

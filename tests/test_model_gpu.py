@@ -526,9 +526,9 @@ def test_persistent_pass_is_bit_identical_to_kernel_by_kernel(shape_name, dtype)
 
 @pytest.mark.parametrize("shape_name", ["small", "tinyllama-1.1b"])
 def test_gemm_prefill_matches_chunked_prefill(shape_name):
-    """Prompts longer than 16 tokens are prefilled in 128-row GEMM passes, from 192 tokens on layer by layer over the
-    whole prompt (one matrix product per projection, csrc/mm.hip); switched off, in 16-row passes of the decode
-    kernels.  Same math, different K summation order: caches and the first token's hidden state agree to 16-bit
+    """Prompts longer than 16 tokens are prefilled in one 128-row GEMM pass, from 129 tokens on layer by layer over the
+    whole prompt (one matrix product per projection, csrc/mm.hip; the d-column projections of a short prompt in K
+    ranges added by a row kernel); switched off, in 16-row passes of the decode kernels.  Same math, different K summation order: caches and the first token's hidden state agree to 16-bit
     rounding noise."""
     shape = get_shape(shape_name)
     if shape_name == "tinyllama-1.1b":
@@ -538,12 +538,12 @@ def test_gemm_prefill_matches_chunked_prefill(shape_name):
     eng = model.engine
     assert eng.get_tuning("gemm_prefill") == 1
     g = torch.Generator().manual_seed(9)
-    assert eng.get_tuning("rows_prefill_min") == 192           # from here on the prompt goes through the layers in whole-prompt passes
-    for plen in (17, 64, 65, 200, 333):
+    assert eng.get_tuning("rows_prefill_min") == 129           # from here on the prompt goes through the layers in whole-prompt passes
+    for plen in (17, 64, 65, 129, 200, 333):
         ids = torch.randint(3, shape.vocab_size, (1, plen), generator=g).cuda()
         caches = {}
         for mode in (2, 1):
-            eng.set_tuning(gemm_prefill=mode, rows_prefill_min=192 if mode == 2 else 1)
+            eng.set_tuning(gemm_prefill=mode, rows_prefill_min=129 if mode == 2 else 1)
             eng.k_cache.zero_(); eng.v_cache.zero_(); eng.ak_cache.zero_(); eng.av_cache.zero_()
             out, st = eng.generate(ids[0], 1, mode="kangaroo")
             torch.cuda.synchronize()
@@ -552,7 +552,7 @@ def test_gemm_prefill_matches_chunked_prefill(shape_name):
         for a, b in zip(caches[2][:4], caches[1][:4]):
             assert float(b.abs().max()) > 0
             assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max())
-    eng.set_tuning(gemm_prefill=2, rows_prefill_min=192)
+    eng.set_tuning(gemm_prefill=2, rows_prefill_min=129)
 
 
 def test_full_size_7b_losslessness_and_determinism():
