@@ -356,9 +356,11 @@ int kg_train_rmsnorm_bwd(int dtype, const void* dy, const void* x, const float* 
  * tables [S][head_dim/2] fp32; inverse != 0 applies the adjoint (backward pass). */
 int kg_train_rope(int dtype, void* x, long long rows, int S, int n_heads, int head_dim, const float* cos_t, const float* sin_t, int inverse, void* stream);
 /* Attention probabilities in place over the scores [B][H][S][S] (kangaroo/adapter.py:195-211): softmax(scale * s) over
- * the keys j <= i with key_mask[b][j] != 0 (causal + padding masks of :38-67,327-348), zeros elsewhere.  S <= 4096. */
+ * the keys j <= i with key_mask[b][j] != 0 (causal + padding masks of :38-67,327-348), zeros for the other keys up to the
+ * end of the 256-column block that holds the diagonal; the columns beyond that block are NOT written (the causal products
+ * of kg_matmul_nt_heads never read them).  S <= 4096. */
 int kg_train_softmax_fwd(int dtype, void* scores, const int* key_mask, int B, int H, int S, float scale, void* stream);
-/* dscores = scale * p * (dp - sum(dp * p)) written over dprobs. */
+/* dscores = scale * p * (dp - sum(dp * p)) written over dprobs, over the same columns as kg_train_softmax_fwd writes. */
 int kg_train_softmax_bwd(int dtype, const void* probs, void* dprobs, int B, int H, int S, float scale, void* stream);
 /* train.py:265-279 for rows of out-logits and target-logits [rows][vocab]: row_loss = -sum_v softmax(t)_v log_softmax(o)_v,
  * row_acc = sum_v min(softmax(t)_v, softmax(o)_v), and the gradient grad_scale * (softmax(o) - softmax(t)) written over
@@ -371,6 +373,10 @@ int kg_train_softce(int dtype, void* logits_out, const void* logits_tgt, const i
 /* y = y + x on n 16-bit elements (n a multiple of 8, 16-byte aligned), rounded once: the residual add of
  * kangaroo/adapter.py:304 after the o_proj product. */
 int kg_train_add(int dtype, void* y, const void* x, long long n, void* stream);
+/* Raises *flag to 1 when any of the n fp32 values is an infinity or a NaN, and leaves it alone otherwise (several tensors
+ * share one flag; the caller clears it).  The flag is what kg_train_adamw's `skip` reads: torch.cuda.amp.GradScaler drops a
+ * step whose gradients overflowed, which accelerate does for the reference's fp16 runs (train.py:46-47,285-287). */
+int kg_train_nonfinite(const float* g, long long n, int* flag, void* stream);
 /* accelerator.clip_grad_value_(clip) + torch.optim.AdamW step `step` (1-based) on n fp32 parameters (train.py:227,285-286);
  * grad_dtype 0 fp16, 1 bf16, 2 fp32, multiplied by inv_scale first; p16 (may be NULL) receives the 16-bit copy
  * (copy_dtype) that the GEMMs read.  skip (device, may be NULL): a non-zero word makes the call a no-op, read when the kernel

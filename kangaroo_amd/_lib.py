@@ -102,6 +102,7 @@ SYMBOLS = {
     "kg_train_softmax_bwd": (_I, [_I, _VP, _VP, _I, _I, _I, _F, _VP]),
     "kg_train_softce": (_I, [_I, _VP, _VP, _VP, _I, _I, C.c_longlong, _F, _VP, _VP, _VP, _VP]),
     "kg_train_add": (_I, [_I, _VP, _VP, C.c_longlong, _VP]),
+    "kg_train_nonfinite": (_I, [_VP, C.c_longlong, _VP, _VP]),
     "kg_train_adamw": (_I, [_VP, _VP, _VP, _VP, _I, _F, _F, _F, _F, _F, _F, _F, _I, C.c_longlong, _VP, _I, _VP, _VP]),
     "kg_generate": (_I, [_VP, _I, C.POINTER(C.c_int32), _I, _I, _I, _I, _D, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I,
                          C.POINTER(KgGenResult), _VP]),

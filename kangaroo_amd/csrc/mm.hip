@@ -139,7 +139,7 @@ template <int DT, int BM, int BN, int WM, int WN, int BMODE, bool OUT_F32>
 __global__ void __launch_bounds__(WM * WN * 64) kg_mm_kernel(const KgMmArgs a) {
     constexpr bool PACKED_B = (BMODE == 1), KMAJOR_B = (BMODE == 2);
     typedef KgT<DT> T;
-    constexpr int MM_BM = BM, MM_BN = BN, NTHR = WM * WN * 64;
+    constexpr int MM_BM = BM, NTHR = WM * WN * 64;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;            // MFMA tiles of a wave
     constexpr int PA = BM * 8 / NTHR, PB = BN * 8 / NTHR;          // 16-byte pieces per thread and step
     constexpr int A_BYTES = BM * MM_BK * 2, STAGE = (BM + BN) * MM_BK * 2;

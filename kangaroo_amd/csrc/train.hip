@@ -178,7 +178,8 @@ __global__ void rope_kernel(unsigned short* x, size_t rows, int S, int n_heads, 
 }
 
 // Row (b, h, i) of the scores [B][H][S][S]: p_j = softmax_j(scale * s_j) over the keys j <= i with
-// key_mask[b][j] != 0 (the causal mask plus the padding mask of kangaroo/adapter.py:327-348), zeros elsewhere.
+// key_mask[b][j] != 0 (the causal mask plus the padding mask of kangaroo/adapter.py:327-348), zeros elsewhere up to the end
+// of the 256-column block of the diagonal (columns beyond it are left as they are).
 // Thread t owns the pieces t, t + 256, ... (S <= 4096); pieces wholly in the future are never read.
 template <int DT, int W>
 __global__ void __launch_bounds__(TB) softmax_fwd_kernel(unsigned short* s, const int* key_mask, int H, int S, float scale) {
@@ -222,10 +223,13 @@ __global__ void __launch_bounds__(TB) softmax_fwd_kernel(unsigned short* s, cons
         for (int e = 0; e < W; ++e) { v[c][e] = (v[c][e] == -INFINITY) ? 0.f : __expf(v[c][e] - mx); sum += v[c][e]; }
     sum = block_sum(sum, red);
     const float inv = sum > 0.f ? 1.f / sum : 0.f;
+    // zeros are written up to the end of the 256-column block that holds the diagonal: the products that read the
+    // probabilities walk the keys in tiles of at most 256 up to the tile of the diagonal and never look beyond it
+    const int lim = min(S, ((i >> 8) + 1) << 8);
 #pragma unroll
     for (int c = 0; c < NP; ++c) {
         const int j0 = (threadIdx.x + c * TB) * W;
-        if (j0 < S) {
+        if (j0 < lim) {
 #pragma unroll
             for (int e = 0; e < W; ++e) v[c][e] *= inv;
             storew<DT, W>(sr + j0, v[c]);
@@ -258,10 +262,11 @@ __global__ void __launch_bounds__(TB) softmax_bwd_kernel(const unsigned short* p
         }
     }
     dot = block_sum(dot, red);
+    const int lim = min(S, ((i >> 8) + 1) << 8);        // as the forward kernel: nothing reads beyond the diagonal's 256-column block
 #pragma unroll
     for (int c = 0; c < NP; ++c) {
         const int j0 = (threadIdx.x + c * TB) * W;
-        if (j0 < S) {
+        if (j0 < lim) {
             float o[W];
 #pragma unroll
             for (int e = 0; e < W; ++e) o[e] = scale * pv[c][e] * (dv[c][e] - dot);
@@ -373,6 +378,13 @@ __global__ void add16_kernel(unsigned short* y, const unsigned short* x, size_t 
     ((kg_u4*)y)[i] = __builtin_bit_cast(kg_u4, o);
 }
 
+// *flag |= 1 when a value of g is an infinity or a NaN (the exponent bits all set); flag is only ever raised here
+__global__ void nonfinite_kernel(const unsigned* g, size_t n, int* flag) {
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) bad |= (g[i] & 0x7f800000u) == 0x7f800000u;
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
 int done(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { kg_set_error(what, e); return -2; }
@@ -462,6 +474,13 @@ extern "C" int kg_train_add(int dtype, void* y, const void* x, long long n, void
     if (dtype == KG_F16) hipLaunchKernelGGL(add16_kernel<KG_F16>, grid, dim3(256), 0, st, (unsigned short*)y, (const unsigned short*)x, n8);
     else hipLaunchKernelGGL(add16_kernel<KG_BF16>, grid, dim3(256), 0, st, (unsigned short*)y, (const unsigned short*)x, n8);
     return done("kg_train_add");
+}
+
+extern "C" int kg_train_nonfinite(const float* g, long long n, int* flag, void* stream) {
+    if (!g || !flag || n < 1) return -1;
+    const size_t blocks = ((size_t)n + 255) / 256;
+    hipLaunchKernelGGL(nonfinite_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, (const unsigned*)g, (size_t)n, flag);
+    return done("kg_train_nonfinite");
 }
 
 // grad_dtype: KG_F16 / KG_BF16 / 2 (fp32); copy_dtype: KG_F16 / KG_BF16 (p16 may be NULL); step is 1-based.

@@ -333,7 +333,9 @@ class AdapterTrainer:
         # A gradient that is not finite (an fp16 overflow under the constant loss scale) must not reach the moments: the
         # reference's GradScaler drops such a step and its schedule step.  The gradients are the all-reduced ones, so every
         # rank sees the same flag; the update kernels read it on the device, the host learns of it with the step's sums.
-        bad = torch.stack([(~torch.isfinite(g)).any() for g in grads.values()]).any().to(torch.int32).reshape(1)
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        for g in grads.values():
+            _lib.check(self.lib.kg_train_nonfinite(self._p(g), g.numel(), self._p(bad), self._st()), "kg_train_nonfinite")
         for key, g in grads.items():
             p16 = self.w16.get(key)
             _lib.check(self.lib.kg_train_adamw(self._p(self.p[key]), self._p(self.m[key]), self._p(self.v[key]), self._p(g), 2, inv_scale, self.clip, lr,
