@@ -651,13 +651,40 @@ void kg_mm_init() {
     (void)hipGetLastError();
 }
 
-// out[b][c][r] = in[b][r][c] for 16-bit elements: 64 x 64 tiles through LDS, both sides in whole lines
+// out[b][c][r] = in[b][r][c] for 16-bit elements: 64 x 64 tiles through LDS, both sides in whole lines.  WIDE: both matrices in
+// 16-byte pieces (R, Cn, the strides and the batch strides multiples of 8, bases 16-byte aligned): a thread loads 8 consecutive
+// columns of a row and stores 8 consecutive rows of a column, gathered from LDS rows 65 words apart (conflict-free).
+template <bool WIDE>
 __global__ void __launch_bounds__(256) kg_transpose16_kernel(const unsigned short* in, unsigned short* out, int R, int Cn, long long ld_in, long long ld_out,
                                                              long long s_in, long long s_out) {
-    __shared__ unsigned short t[64][66];
+    __shared__ unsigned short t[64][130];                  // pitch 65 words
     const unsigned short* ib = in + (size_t)blockIdx.z * s_in;
     unsigned short* ob = out + (size_t)blockIdx.z * s_out;
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    if (WIDE) {
+        const int ch = threadIdx.x & 7, rr = threadIdx.x >> 3;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = r0 + rr + 32 * p, c = c0 + 8 * ch;
+            kg_u4 v = kg_u4{0u, 0u, 0u, 0u};
+            if (r < R && c < Cn) v = *(const kg_u4*)(ib + (size_t)r * ld_in + c);
+            const kg_us8 h = __builtin_bit_cast(kg_us8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[8 * ch + e][2 * (rr + 32 * p)] = h[e];        // t[column][row], one element per word
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int c = c0 + rr + 32 * p, r = r0 + 8 * ch;
+            if (c < Cn && r < R) {
+                kg_us8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = t[rr + 32 * p][2 * (8 * ch + e)];
+                *(kg_u4*)(ob + (size_t)c * ld_out + r) = __builtin_bit_cast(kg_u4, o);
+            }
+        }
+        return;
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
         const int r = r0 + i, c = c0 + tx;
@@ -672,6 +699,8 @@ __global__ void __launch_bounds__(256) kg_transpose16_kernel(const unsigned shor
 int kg_launch_transpose16(const void* in, void* out, int R, int Cn, long long ld_in, long long ld_out, int batch, long long s_in, long long s_out, hipStream_t st) {
     if (!in || !out || R < 1 || Cn < 1 || batch < 1 || batch > 65535) return -1;
     const dim3 grid((Cn + 63) / 64, (R + 63) / 64, batch);
-    hipLaunchKernelGGL(kg_transpose16_kernel, grid, dim3(256), 0, st, (const unsigned short*)in, (unsigned short*)out, R, Cn, ld_in, ld_out, s_in, s_out);
+    const bool wide = ((R | Cn | ld_in | ld_out | s_in | s_out) & 7) == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    if (wide) hipLaunchKernelGGL(kg_transpose16_kernel<true>, grid, dim3(256), 0, st, (const unsigned short*)in, (unsigned short*)out, R, Cn, ld_in, ld_out, s_in, s_out);
+    else hipLaunchKernelGGL(kg_transpose16_kernel<false>, grid, dim3(256), 0, st, (const unsigned short*)in, (unsigned short*)out, R, Cn, ld_in, ld_out, s_in, s_out);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -98,6 +98,11 @@ def test_causal_and_head_strided_products(dtype, tile, monkeypatch):
     out = torch.empty(3, 200, 70, dtype=dtype, device=DEV)
     _lib.check(lib.kg_transpose16(T_.data_ptr(), out.data_ptr(), 70, 200, 200, 70, 3, 70 * 200, 70 * 200, st()), "kg_transpose16")
     assert torch.equal(out, T_.transpose(1, 2))
+    # whole 16-byte pieces on both sides (the fast form), ragged tile edges, rows inside wider rows
+    Tw = torch.randn(2, 136, 328, device=DEV, generator=g).to(dtype)
+    out = torch.zeros(2, 200, 136, dtype=dtype, device=DEV)
+    _lib.check(lib.kg_transpose16(Tw[:, :, 64:].data_ptr(), out.data_ptr(), 136, 200, 328, 136, 2, 136 * 328, 200 * 136, st()), "kg_transpose16")
+    assert torch.equal(out, Tw[:, :, 64:264].transpose(1, 2))
 
 
 def test_bad_shapes_are_refused():
