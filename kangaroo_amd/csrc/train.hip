@@ -275,6 +275,93 @@ __global__ void __launch_bounds__(TB) softmax_bwd_kernel(const unsigned short* p
     }
 }
 
+// The same two kernels with a WAVE per row (S a multiple of 8, at most 512 * NP keys; NP pieces of 8 per lane): no block
+// barrier and no LDS, four rows per block.  A row of 2048 keys is 4 KB: a block per row spends its time in two block-wide
+// reductions, not on memory.
+template <int DT, int NP>
+__global__ void __launch_bounds__(256) softmax_fwd_wave_kernel(unsigned short* s, const int* key_mask, size_t rows, int H, int S, float scale) {
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(row % S), b = (int)(row / ((size_t)H * S));
+    unsigned short* sr = s + row * S;
+    const int* km = key_mask + (size_t)b * S;
+    float v[NP][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        const int j0 = (lane + c * 64) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[c][e] = -INFINITY;
+        if (j0 <= i && j0 < S) {
+            float f[8];
+            loadw<DT, 8>(sr + j0, f);
+            const kg_u4 a = *(const kg_u4*)(km + j0), b4 = *(const kg_u4*)(km + j0 + 4);
+            const unsigned kmv[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = j0 + e <= i && kmv[e] != 0;
+                v[c][e] = ok ? f[e] * scale : -INFINITY;
+                mx = fmaxf(mx, v[c][e]);
+            }
+        }
+    }
+    mx = kg_wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NP; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[c][e] = (v[c][e] == -INFINITY) ? 0.f : __expf(v[c][e] - mx); sum += v[c][e]; }
+    sum = kg_wave_sum(sum);
+    const float inv = sum > 0.f ? 1.f / sum : 0.f;
+    const int lim = min(S, ((i >> 8) + 1) << 8);
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        const int j0 = (lane + c * 64) * 8;
+        if (j0 < lim) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[c][e] *= inv;
+            storew<DT, 8>(sr + j0, v[c]);
+        }
+    }
+}
+template <int DT, int NP>
+__global__ void __launch_bounds__(256) softmax_bwd_wave_kernel(const unsigned short* p, unsigned short* dp, size_t rows, int S, float scale) {
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(row % S);
+    const unsigned short* pr = p + row * S;
+    unsigned short* dr = dp + row * S;
+    float pv[NP][8], dv[NP][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        const int j0 = (lane + c * 64) * 8;
+        if (j0 <= i && j0 < S) {
+            loadw<DT, 8>(pr + j0, pv[c]);
+            loadw<DT, 8>(dr + j0, dv[c]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dot += pv[c][e] * dv[c][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { pv[c][e] = 0.f; dv[c][e] = 0.f; }
+        }
+    }
+    dot = kg_wave_sum(dot);
+    const int lim = min(S, ((i >> 8) + 1) << 8);
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        const int j0 = (lane + c * 64) * 8;
+        if (j0 < lim) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = scale * pv[c][e] * (dv[c][e] - dot);
+            storew<DT, 8>(dr + j0, o);
+        }
+    }
+}
+
 // One row of out-logits o and target-logits t (train.py:265-279):
 //   loss = lse(o) - sum_v softmax(t)_v o_v,   acc = sum_v min(softmax(t)_v, softmax(o)_v),
 //   dlogits_v = grad_scale * (softmax(o)_v - softmax(t)_v)   (written over o; zeros when the row's loss_mask is 0),
@@ -433,24 +520,36 @@ extern "C" int kg_train_rope(int dtype, void* x, long long rows, int S, int n_he
 extern "C" int kg_train_softmax_fwd(int dtype, void* scores, const int* key_mask, int B, int H, int S, float scale, void* stream) {
     if (!scores || !key_mask || B < 1 || H < 1 || S < 1 || S > 16 * TB) return -1;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)((size_t)B * H * S));
+    const size_t rows = (size_t)B * H * S;
+    const dim3 grid((unsigned)rows);
     const bool wide = (S & 7) == 0 && (((uintptr_t)scores | (uintptr_t)key_mask) & 15) == 0;
-    if (dtype == KG_F16) { if (wide) hipLaunchKernelGGL((softmax_fwd_kernel<KG_F16, 8>), grid, dim3(TB), 0, st, (unsigned short*)scores, key_mask, H, S, scale);
-                           else hipLaunchKernelGGL((softmax_fwd_kernel<KG_F16, 1>), grid, dim3(TB), 0, st, (unsigned short*)scores, key_mask, H, S, scale); }
-    else { if (wide) hipLaunchKernelGGL((softmax_fwd_kernel<KG_BF16, 8>), grid, dim3(TB), 0, st, (unsigned short*)scores, key_mask, H, S, scale);
-           else hipLaunchKernelGGL((softmax_fwd_kernel<KG_BF16, 1>), grid, dim3(TB), 0, st, (unsigned short*)scores, key_mask, H, S, scale); }
+    if (wide) {
+        const dim3 gw((unsigned)((rows + 3) / 4));
+        unsigned short* sc = (unsigned short*)scores;
+#define KG_SMF(D, N) hipLaunchKernelGGL((softmax_fwd_wave_kernel<D, N>), gw, dim3(256), 0, st, sc, key_mask, rows, H, S, scale)
+        if (dtype == KG_F16) { if (S <= 512) KG_SMF(KG_F16, 1); else if (S <= 1024) KG_SMF(KG_F16, 2); else if (S <= 2048) KG_SMF(KG_F16, 4); else KG_SMF(KG_F16, 8); }
+        else { if (S <= 512) KG_SMF(KG_BF16, 1); else if (S <= 1024) KG_SMF(KG_BF16, 2); else if (S <= 2048) KG_SMF(KG_BF16, 4); else KG_SMF(KG_BF16, 8); }
+#undef KG_SMF
+    } else if (dtype == KG_F16) hipLaunchKernelGGL((softmax_fwd_kernel<KG_F16, 1>), grid, dim3(TB), 0, st, (unsigned short*)scores, key_mask, H, S, scale);
+    else hipLaunchKernelGGL((softmax_fwd_kernel<KG_BF16, 1>), grid, dim3(TB), 0, st, (unsigned short*)scores, key_mask, H, S, scale);
     return done("kg_train_softmax_fwd");
 }
 
 extern "C" int kg_train_softmax_bwd(int dtype, const void* probs, void* dprobs, int B, int H, int S, float scale, void* stream) {
     if (!probs || !dprobs || B < 1 || H < 1 || S < 1 || S > 16 * TB) return -1;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)((size_t)B * H * S));
+    const size_t rows = (size_t)B * H * S;
+    const dim3 grid((unsigned)rows);
     const bool wide = (S & 7) == 0 && (((uintptr_t)probs | (uintptr_t)dprobs) & 15) == 0;
-    if (dtype == KG_F16) { if (wide) hipLaunchKernelGGL((softmax_bwd_kernel<KG_F16, 8>), grid, dim3(TB), 0, st, (const unsigned short*)probs, (unsigned short*)dprobs, S, scale);
-                           else hipLaunchKernelGGL((softmax_bwd_kernel<KG_F16, 1>), grid, dim3(TB), 0, st, (const unsigned short*)probs, (unsigned short*)dprobs, S, scale); }
-    else { if (wide) hipLaunchKernelGGL((softmax_bwd_kernel<KG_BF16, 8>), grid, dim3(TB), 0, st, (const unsigned short*)probs, (unsigned short*)dprobs, S, scale);
-           else hipLaunchKernelGGL((softmax_bwd_kernel<KG_BF16, 1>), grid, dim3(TB), 0, st, (const unsigned short*)probs, (unsigned short*)dprobs, S, scale); }
+    if (wide) {
+        const dim3 gw((unsigned)((rows + 3) / 4));
+        const unsigned short* pp = (const unsigned short*)probs; unsigned short* dpp = (unsigned short*)dprobs;
+#define KG_SMB(D, N) hipLaunchKernelGGL((softmax_bwd_wave_kernel<D, N>), gw, dim3(256), 0, st, pp, dpp, rows, S, scale)
+        if (dtype == KG_F16) { if (S <= 512) KG_SMB(KG_F16, 1); else if (S <= 1024) KG_SMB(KG_F16, 2); else if (S <= 2048) KG_SMB(KG_F16, 4); else KG_SMB(KG_F16, 8); }
+        else { if (S <= 512) KG_SMB(KG_BF16, 1); else if (S <= 1024) KG_SMB(KG_BF16, 2); else if (S <= 2048) KG_SMB(KG_BF16, 4); else KG_SMB(KG_BF16, 8); }
+#undef KG_SMB
+    } else if (dtype == KG_F16) hipLaunchKernelGGL((softmax_bwd_kernel<KG_F16, 1>), grid, dim3(TB), 0, st, (const unsigned short*)probs, (unsigned short*)dprobs, S, scale);
+    else hipLaunchKernelGGL((softmax_bwd_kernel<KG_BF16, 1>), grid, dim3(TB), 0, st, (const unsigned short*)probs, (unsigned short*)dprobs, S, scale);
     return done("kg_train_softmax_bwd");
 }
 
