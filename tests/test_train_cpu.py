@@ -117,6 +117,31 @@ def test_gradient_mean_over_two_gloo_ranks():
         assert torch.equal(out[0][i], out[1][i])
 
 
+def _epoch_rank_main(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=30))
+    sync = T.GradSync()
+    seen = []
+    for batch in T.epoch_batches(11, 2, 3, rank, world):      # 11 files, 2 ranks x 2 per batch: 6 batches, no multiple of 2 x 2 files
+        (g32,) = sync.start([torch.full((4,), float(len(seen) + 1 + rank))])       # what a step does: one collective per bucket
+        sync.finish()
+        seen.append((batch, float(g32[0])))
+    out[rank] = seen
+    dist.destroy_process_group()
+
+
+def test_an_epoch_on_two_gloo_ranks_ends_together():
+    """Two ranks walk one epoch's batches with a gradient all-reduce per step, as train_epoch does: with unequal step counts
+    the rank with the extra batch would sit in its collective until the 30 s timeout and the spawn would fail."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_epoch_rank_main, args=(world, port, out), nprocs=world, join=True)
+    assert len(out[0]) == len(out[1]) == 3
+    assert {i for r in range(world) for b, _ in out[r] for i in b} == set(range(11))
+    assert [m for _, m in out[0]] == [m for _, m in out[1]] == [1.5, 2.5, 3.5]        # the mean of step + rank over both ranks
+
+
 def test_head_weight_alone_is_read_from_its_shard(tmp_path):
     # train.py:69-86 opens only the shard that holds lm_head.weight
     import json
