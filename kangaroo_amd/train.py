@@ -109,8 +109,10 @@ class GradSync:
 
     def start(self, tensors: List[torch.Tensor]) -> List[torch.Tensor]:
         """tensors -> fp32 views of one flat bucket being reduced."""
+        if self.world == 1:                                   # nothing to exchange: the gradients as they are
+            return [t if t.dtype == torch.float32 else t.to(torch.float32) for t in tensors]
         flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
-        work = self.dist.all_reduce(flat, group=self.group, async_op=True) if self.world > 1 else None
+        work = self.dist.all_reduce(flat, group=self.group, async_op=True)
         self.pending.append((flat, work))
         out, off = [], 0
         for t in tensors:
@@ -341,7 +343,7 @@ class AdapterTrainer:
             _lib.check(self.lib.kg_train_adamw(self._p(self.p[key]), self._p(self.m[key]), self._p(self.v[key]), self._p(g), 2, inv_scale, self.clip, lr,
                                                self.betas[0], self.betas[1], self.adam_eps, self.wd, self.t, self.p[key].numel(), self._p(p16), self.dt,
                                                self._p(bad), self._st()), "kg_train_adamw")
-        self.last_grads = {k: g * inv_scale for k, g in grads.items()}                 # unscaled, before clipping (tests, logging)
+        self._last = (grads, inv_scale)
         sums = torch.stack([row_loss.sum(), row_acc.sum()] + [((row_rank >= 0) & (row_rank < k)).sum().float() for k in (1, 2, 3)] + [bad[0].float()]).tolist()
         skipped = sums[5] != 0.0
         if skipped:
@@ -351,6 +353,12 @@ class AdapterTrainer:
         # top-k counts as train.py:298-309 accumulates them (the target token = argmax of the target head)
         return {"loss": sums[0] / n_loss, "prob_acc": sums[1] / n_loss, "lr": lr, "tokens": B * S0, "loss_positions": n_loss,
                 "top1_correct": int(sums[2]), "top2_correct": int(sums[3]), "top3_correct": int(sums[4]), "skipped": skipped}
+
+    @property
+    def last_grads(self) -> Dict[str, torch.Tensor]:
+        """The last step's gradients, unscaled, before clipping (tests, logging); computed when asked for."""
+        grads, inv_scale = self._last
+        return {k: g * inv_scale for k, g in grads.items()}
 
     def state_dict(self, dtype=None) -> Dict[str, torch.Tensor]:
         return {PARAM_KEYS[k]: (v.to(dtype) if dtype is not None else v.clone()) for k, v in self.p.items()}
