@@ -451,8 +451,190 @@ __global__ void __launch_bounds__(256) kg_attn_rows_kernel(const unsigned short*
     }
 }
 
+// The same attention for head_dim 128 with the keys shared: a block of four waves owns 128 query rows (32 per wave, two
+// MFMA column tiles) and walks the keys in tiles of 64 that are staged ONCE per block in LDS by loads that write LDS
+// directly (K rows of 256 bytes, V^T rows of 128 bytes; two buffers of 32 KB; the XOR swizzles that keep the fragment
+// reads off each other's banks sit on the source addresses).  Per tile and wave: S^T = K q^T (rows of the MFMA = keys,
+// assigned so that the 8 probabilities a lane ends up with are 8 consecutive keys), online softmax per query column (a
+// lane owns ONE query per column tile: no cross-lane traffic but the two steps of the column maximum), O^T += V^T P^T.
+// Arithmetic and rounding points are attn_tile_compute's.  Row blocks are dealt longest first.
+template <int DT>
+__global__ void __launch_bounds__(256, 2) kg_attn_rows128_kernel(const unsigned short* q, const unsigned short* k_cache, const unsigned short* v_cache, unsigned short* out,
+                                                                  int rows, int pos0, int H, int Hkv, int t_max) {
+    typedef KgT<DT> T;
+    constexpr int HD = 128, KT = 64, TILE = 2 * KT * HD * 2;      // bytes of one K + V^T tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.y, kvh = h / (H / Hkv);
+    const int nblk = (rows + 127) >> 7, rb = nblk - 1 - (int)blockIdx.x;
+    const int r0 = 128 * rb + 32 * wave;                          // this wave's first row
+    const int len_blk = pos0 + min(rows, 128 * rb + 128);         // keys the block walks
+    const int len_w = pos0 + min(rows, r0 + 32);                  // keys this wave's rows can see (<= 0 rows: nothing)
+    const __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, (int)((size_t)rows * H * HD * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc((void*)(k_cache + (size_t)kvh * t_max * HD), 0, (int)((size_t)t_max * HD * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void*)(v_cache + (size_t)kvh * HD * t_max), 0, (int)((size_t)t_max * HD * 2), 0x00020000);
+    kg_u4 qf[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)     // rows beyond the prompt are out of range: zeros
+            qf[qt][ks] = __builtin_amdgcn_raw_buffer_load_b128(qr, (unsigned)((((size_t)(r0 + 16 * qt + fr) * H + h) * HD + 32 * ks + 8 * fg) * 2), 0, 0);
+    // ---- staging: per tile and thread 4 loads of K (4 rows of 256 B per wave-level load) and 4 of V^T (8 rows of 128 B) ----
+    unsigned k_src[4], v_src[4];           // byte offsets at tile 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kr_ = (4 * i + wave) * 4 + (lane >> 4), ks_ = lane & 15;                   // LDS row (key), 16-byte slot
+        k_src[i] = (unsigned)(((size_t)kr_ * HD + 8 * (ks_ ^ (4 * ((kr_ >> 3) & 3) + (kr_ & 3)))) * 2);
+        const int vr_ = (4 * i + wave) * 8 + (lane >> 3), vs_ = lane & 7;                    // LDS row (head dim), 16-byte slot
+        v_src[i] = (unsigned)(((size_t)vr_ * t_max + 8 * (vs_ ^ ((vr_ >> 1) & 7))) * 2);
+    }
+    const int ntile = (len_blk + KT - 1) / KT;
+    auto request = [&](int t) {
+        char* buf = smem + (t & 1) * TILE;
+        const bool ok = t < ntile;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(kr, (__attribute__((address_space(3))) void*)(buf + (4 * i + wave) * 1024), 16,
+                                                     ok ? k_src[i] + (unsigned)((size_t)t * KT * HD * 2) : 0xFFFFFFFFu, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (__attribute__((address_space(3))) void*)(buf + KT * HD * 2 + (4 * i + wave) * 1024), 16,
+                                                     ok ? v_src[i] + (unsigned)(t * KT * 2) : 0xFFFFFFFFu, 0, 0, 0);
+    };
+    const float inv_scale = sqrtf((float)HD), rcp_scale = 1.0f / inv_scale;
+    float mrun[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+    kg_f4 O[2][8];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) O[qt][b] = kg_f4{0.f, 0.f, 0.f, 0.f};
+    int lim[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) lim[qt] = (r0 + 16 * qt + fr < rows) ? pos0 + r0 + 16 * qt + fr : -1;
+
+    request(0);
+    for (int t = 0; t < ntile; ++t) {
+        request(t + 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // tile t has landed (this thread's share) ...
+        __builtin_amdgcn_s_barrier();                             // ... and everybody's
+        const int tb = t * KT;
+        if (tb < len_w) {                                         // tiles beyond this wave's last row: nothing to add
+            const char* kb = smem + (t & 1) * TILE;
+            const char* vb = kb + KT * HD * 2;
+            // Only the tiles that reach a row's diagonal need the causal test (rows of the wave: r0 .. r0 + 31).
+            const bool diag = tb + KT - 1 > pos0 + r0;
+            float sc[2][16];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                // MFMA row fr of score tile kt is key 32 (kt >> 1) + 8 (fr >> 2) + 4 (kt & 1) + (fr & 3)
+                const int krow = 32 * (kt >> 1) + 8 * (fr >> 2) + 4 * (kt & 1) + (fr & 3);
+                kg_u4 kf[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const kg_u4*)(kb + krow * 256 + (((4 * ks + fg) ^ fr) << 4));
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    kg_f4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) d = T::mfma(kf[ks], qf[qt][ks], d);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // q.k^T stored, then divided by sqrt(hd) and stored.  The quotient by a constant: one product with the
+                        // rounded reciprocal and one correction step give the correctly rounded fp32 quotient (Markstein), the
+                        // same bits as the division.
+                        const float x = kg_round<DT>(d[e]);
+                        const float q0 = x * rcp_scale;
+                        sc[qt][4 * kt + e] = kg_round<DT>(__builtin_fmaf(__builtin_fmaf(-q0, inv_scale, x), rcp_scale, q0));
+                    }
+                }
+            }
+            if (diag) {
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int key = tb + 32 * (j >> 3) + 8 * fg + (j & 7);       // j = 4 kt + e: 32 (kt >> 1) + 4 (kt & 1) + e
+                        if (key > lim[qt]) sc[qt][j] = -INFINITY;
+                    }
+            }
+            kg_u4 pf[2][2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                float bm = sc[qt][0];
+#pragma unroll
+                for (int j = 1; j < 16; ++j) bm = fmaxf(bm, sc[qt][j]);
+                bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+                bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+                const float mnew = fmaxf(mrun[qt], bm);
+                // exp(x - m) as 2^(x log2 e - m log2 e); a masked score is -inf and gives 0, and so does a first tile's mrun;
+                // a row with no key yet (rows beyond the prompt) keeps m = -inf: its products are never stored
+                const float ml = (mnew == -INFINITY) ? 0.f : mnew * 1.44269504088896340736f;
+                const float scale = __builtin_amdgcn_exp2f(__builtin_fmaf(mrun[qt], 1.44269504088896340736f, -ml));
+                float psum = 0.f;
+                float p[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qt][j], 1.44269504088896340736f, -ml));
+                    psum += p[j];
+                }
+                lsum[qt] = lsum[qt] * scale + psum;
+                mrun[qt] = mnew;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    pf[qt][ks].x = T::from_f(p[8 * ks + 0]) | ((unsigned)T::from_f(p[8 * ks + 1]) << 16); pf[qt][ks].y = T::from_f(p[8 * ks + 2]) | ((unsigned)T::from_f(p[8 * ks + 3]) << 16);
+                    pf[qt][ks].z = T::from_f(p[8 * ks + 4]) | ((unsigned)T::from_f(p[8 * ks + 5]) << 16); pf[qt][ks].w = T::from_f(p[8 * ks + 6]) | ((unsigned)T::from_f(p[8 * ks + 7]) << 16);
+                }
+#pragma unroll
+                for (int b = 0; b < 8; ++b) O[qt][b] = O[qt][b] * scale;
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                kg_u4 vf[2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) vf[ks] = *(const kg_u4*)(vb + (16 * b + fr) * 128 + (((4 * ks + fg) ^ (((16 * b + fr) >> 1) & 7)) << 4));
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) O[qt][b] = T::mfma(vf[ks], pf[qt][ks], O[qt][b]);     // D[d = 4 fg + e][q = fr]
+            }
+        }
+        __builtin_amdgcn_s_barrier();                             // everybody has left buffer t & 1: the next request may refill it
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = lsum[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int m = r0 + 16 * qt + fr;
+        if (m < rows) {
+            const float linv = 1.0f / l;
+            unsigned short* dst = out + ((size_t)m * H + h) * HD + 4 * fg;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const kg_f4 o = O[qt][b] * linv;
+                *(unsigned long long*)(dst + 16 * b) = (unsigned long long)T::from_f(o[0]) | ((unsigned long long)T::from_f(o[1]) << 16) |
+                                                       ((unsigned long long)T::from_f(o[2]) << 32) | ((unsigned long long)T::from_f(o[3]) << 48);
+            }
+        }
+    }
+}
+
 int kg_launch_attn_rows(const void* q, const void* k_cache, const void* v_cache, void* out, int rows, int pos0, int H, int Hkv, int hd, int t_max, int dtype, hipStream_t st) {
     if (!q || !k_cache || !v_cache || !out || rows < 1 || pos0 < 0 || pos0 + rows > t_max || H % Hkv || (t_max & 31)) return -1;
+    static int use128 = -1;
+    if (use128 < 0) {
+        const char* e = getenv("KG_ATTN_ROWS128");                 // measurements: 0 keeps the one-wave-per-16-rows kernel
+        use128 = (e && atoi(e) == 0) ? 0 : 1;
+        (void)hipFuncSetAttribute((const void*)kg_attn_rows128_kernel<KG_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)kg_attn_rows128_kernel<KG_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    }
+    if (hd == 128 && use128 && (t_max & 63) == 0 && (size_t)t_max * 128 * 2 < 0x7fffffffu) {
+        const dim3 g128((rows + 127) / 128, H);
+        if (dtype == KG_F16) hipLaunchKernelGGL(kg_attn_rows128_kernel<KG_F16>, g128, dim3(256), 65536, st, (const unsigned short*)q, (const unsigned short*)k_cache, (const unsigned short*)v_cache, (unsigned short*)out, rows, pos0, H, Hkv, t_max);
+        else hipLaunchKernelGGL(kg_attn_rows128_kernel<KG_BF16>, g128, dim3(256), 65536, st, (const unsigned short*)q, (const unsigned short*)k_cache, (const unsigned short*)v_cache, (unsigned short*)out, rows, pos0, H, Hkv, t_max);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     const dim3 grid(((rows + 15) / 16 + 3) / 4, H);
 #define KG_AR(D, HD_) hipLaunchKernelGGL((kg_attn_rows_kernel<D, HD_>), grid, dim3(256), 0, st, (const unsigned short*)q, (const unsigned short*)k_cache, (const unsigned short*)v_cache, (unsigned short*)out, rows, pos0, H, Hkv, t_max)
     if (dtype == KG_F16) { switch (hd) { case 32: KG_AR(KG_F16, 32); break; case 64: KG_AR(KG_F16, 64); break; case 128: KG_AR(KG_F16, 128); break; default: return -1; } }
