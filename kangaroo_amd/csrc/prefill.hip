@@ -119,7 +119,9 @@ __global__ void __launch_bounds__(256) kg_rows_rope_kv_kernel(const unsigned sho
     const unsigned short* row = qkv + (size_t)m * N;
     const float* cs = rope_cos + (size_t)pos * half;
     const float* sn = rope_sin + (size_t)pos * half;
-    for (int pr = threadIdx.x; pr < (N >> 1); pr += 256) {
+    // a transposed V cache is written by kg_rows_v_transposed_kernel (whole lines instead of one element per line)
+    const int n_end = v_transposed ? q_dim + kv_dim : N;
+    for (int pr = threadIdx.x; pr < (n_end >> 1); pr += 256) {
         const int n0 = 2 * pr;
         const unsigned v2 = *(const unsigned*)(row + n0);
         float x1 = T::to_f((unsigned short)(v2 & 0xffffu)), x2 = T::to_f((unsigned short)(v2 >> 16));
@@ -150,6 +152,42 @@ __global__ void __launch_bounds__(256) kg_rows_rope_kv_kernel(const unsigned sho
         dst[j + half] = T::from_f(x2);
     }
 }
+// The V rows of the fused q/k/v product into the transposed cache layout [Hkv][hd][t_max]: a block takes 64 consecutive
+// positions of one head, turns them round in LDS and writes 128-byte lines (64 positions of one head dim).  Element 2j of
+// a head's stored row is dim j, element 2j + 1 dim j + hd / 2 (the packed row order of wqkv).
+template <int HD>
+__global__ void __launch_bounds__(256) kg_rows_v_transposed_kernel(const unsigned short* qkv, int rows, int pos0, int N, int v_off, unsigned short* v_cache, int t_max) {
+    __shared__ unsigned short t[HD][66];                   // [dim][position], one spare word per row
+    const int r0 = blockIdx.x * 64, kvh = blockIdx.y;
+    const unsigned short* src = qkv + (size_t)r0 * N + v_off + kvh * HD;
+    constexpr int CPR = HD / 8;                            // 16-byte pieces per stored row
+    for (int c = threadIdx.x; c < 64 * CPR; c += 256) {
+        const int r = c / CPR, ch = c - r * CPR;
+        kg_u4 v = kg_u4{0u, 0u, 0u, 0u};
+        if (r0 + r < rows) v = *(const kg_u4*)(src + (size_t)r * N + 8 * ch);
+        const kg_us8 h = __builtin_bit_cast(kg_us8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = 8 * ch + e, dim = (n >> 1) + (n & 1) * (HD / 2);
+            t[dim][r] = h[e];
+        }
+    }
+    __syncthreads();
+    unsigned short* dst = v_cache + (size_t)kvh * HD * t_max + pos0 + r0;
+    const bool wide = ((pos0 + r0) & 7) == 0 && (t_max & 7) == 0;
+    for (int c = threadIdx.x; c < HD * 8; c += 256) {
+        const int dim = c >> 3, p8 = (c & 7) * 8;
+        if (wide && r0 + p8 + 8 <= rows) {
+            kg_us8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = t[dim][p8 + e];
+            *(kg_u4*)(dst + (size_t)dim * t_max + p8) = __builtin_bit_cast(kg_u4, o);
+        } else {
+            for (int e = 0; e < 8 && r0 + p8 + e < rows; ++e) dst[(size_t)dim * t_max + p8 + e] = t[dim][p8 + e];
+        }
+    }
+}
+
 int kg_launch_rows_rope_kv(const void* qkv, int rows, int pos0, int head_dim, int q_dim, int kv_dim, const float* rope_cos, const float* rope_sin,
                            void* q_out, void* k_cache, void* v_cache, int t_max, int v_transposed, int dtype, hipStream_t st) {
     if (!qkv || !rope_cos || !rope_sin || !q_out || !k_cache || !v_cache || rows < 1 || pos0 < 0 || pos0 + rows > t_max || (head_dim & 1)) return -1;
@@ -157,5 +195,16 @@ int kg_launch_rows_rope_kv(const void* qkv, int rows, int pos0, int head_dim, in
                                             (unsigned short*)q_out, (unsigned short*)k_cache, (unsigned short*)v_cache, t_max, v_transposed);
     else hipLaunchKernelGGL(kg_rows_rope_kv_kernel<KG_BF16>, dim3(rows), dim3(256), 0, st, (const unsigned short*)qkv, pos0, head_dim, q_dim, kv_dim, rope_cos, rope_sin,
                             (unsigned short*)q_out, (unsigned short*)k_cache, (unsigned short*)v_cache, t_max, v_transposed);
+    if (v_transposed) {
+        const int N = q_dim + 2 * kv_dim;
+        if ((N & 7) || (q_dim & 7) || (kv_dim & 7)) return -1;
+        const dim3 grid((rows + 63) / 64, kv_dim / head_dim);
+        switch (head_dim) {
+            case 32: hipLaunchKernelGGL(kg_rows_v_transposed_kernel<32>, grid, dim3(256), 0, st, (const unsigned short*)qkv, rows, pos0, N, q_dim + kv_dim, (unsigned short*)v_cache, t_max); break;
+            case 64: hipLaunchKernelGGL(kg_rows_v_transposed_kernel<64>, grid, dim3(256), 0, st, (const unsigned short*)qkv, rows, pos0, N, q_dim + kv_dim, (unsigned short*)v_cache, t_max); break;
+            case 128: hipLaunchKernelGGL(kg_rows_v_transposed_kernel<128>, grid, dim3(256), 0, st, (const unsigned short*)qkv, rows, pos0, N, q_dim + kv_dim, (unsigned short*)v_cache, t_max); break;
+            default: return -1;
+        }
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
