@@ -336,6 +336,12 @@ int kg_matmul_nt(int dtype, const void* A, const void* B, void* C, int M, int N,
 int kg_matmul_nt_heads(int dtype, const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb, long long ldc,
                        int batch, long long sA, long long sB, long long sC, int batch_inner, long long sA2, long long sB2, long long sC2, int b_inner_div,
                        int b_packed, int out_f32, int causal, float alpha, void* stream);
+/* The same product with K cut into n_ranges ranges of whole 64-steps that run side by side: range r leaves its fp32 partial
+ * product at parts + r * range_stride (elements; >= M * ldc).  For products with few output tiles (the d-column projections
+ * of a short prompt, evaluation/inference_kangaroo.py:30 through kangaroo/adapter.py:222,242): the caller adds the ranges in
+ * range order, which keeps the result independent of how the ranges were scheduled.  b_packed 0 or 1. */
+int kg_matmul_nt_ranges(int dtype, const void* A, const void* B, float* parts, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                        int b_packed, int n_ranges, long long range_stride, void* stream);
 /* out[b][c][r] = in[b][r][c] for 16-bit elements (row strides ld_in / ld_out, batch strides s_in / s_out, in elements). */
 int kg_transpose16(const void* in, void* out, int rows, int cols, long long ld_in, long long ld_out, int batch, long long s_in, long long s_out, void* stream);
 

@@ -92,6 +92,7 @@ SYMBOLS = {
     "kg_matmul_nt": (_I, [_I, _VP, _VP, _VP, _I, _I, _I, C.c_longlong, C.c_longlong, C.c_longlong, _I, C.c_longlong, C.c_longlong, C.c_longlong, _I, _I, _I, _F, _VP]),
     "kg_matmul_nt_heads": (_I, [_I, _VP, _VP, _VP, _I, _I, _I, C.c_longlong, C.c_longlong, C.c_longlong, _I, C.c_longlong, C.c_longlong, C.c_longlong,
                                 _I, C.c_longlong, C.c_longlong, C.c_longlong, _I, _I, _I, _I, _F, _VP]),
+    "kg_matmul_nt_ranges": (_I, [_I, _VP, _VP, _VP, _I, _I, _I, C.c_longlong, C.c_longlong, C.c_longlong, _I, _I, C.c_longlong, _VP]),
     "kg_transpose16": (_I, [_VP, _VP, _I, _I, C.c_longlong, C.c_longlong, _I, C.c_longlong, C.c_longlong, _VP]),
     "kg_bench_op": (_I, [_VP, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_size_t)]),
     "kg_train_rmsnorm_fwd": (_I, [_I, _VP, _VP, _F, _I, _I, _VP, _VP, _VP]),

@@ -1516,6 +1516,24 @@ extern "C" int kg_matmul_nt_heads(int dtype, const void* A, const void* B, void*
     return 0;
 }
 
+extern "C" int kg_matmul_nt_ranges(int dtype, const void* A, const void* B, float* parts, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                                   int b_packed, int n_ranges, long long range_stride, void* stream) {
+    g_err.clear();
+    kg_init_once();
+    if (dtype != KG_F16 && dtype != KG_BF16) return fail(-1, "dtype");
+    if (n_ranges < 1 || n_ranges > 64 || b_packed == 2) return fail(-1, "kg_matmul_nt_ranges: 1..64 ranges, a row-major or packed B");
+    KgMmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.B = B; a.C = parts; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.batch = 1; a.batch_inner = 1; a.b_inner_div = 1; a.b_packed = b_packed; a.out_f32 = 1; a.alpha = 1.0f;
+    a.ksplit = n_ranges; a.sCk = range_stride;
+    { const char* t = getenv("KG_MM_TILE"); a.tile = t ? atoi(t) : 0; if (a.tile != 3) a.tile = 4; }
+    const int rc = kg_launch_mm(a, dtype, (hipStream_t)stream);
+    if (rc == -1) return fail(-1, "kg_matmul_nt_ranges: bad shape (K and the row strides multiples of 8, range_stride >= M * ldc; a packed B needs K % 32 == 0)");
+    if (rc) return fail(rc, "kg_matmul_nt_ranges launch failed");
+    return 0;
+}
+
 extern "C" int kg_transpose16(const void* in, void* out, int rows, int cols, long long ld_in, long long ld_out, int batch, long long s_in, long long s_out, void* stream) {
     g_err.clear();
     const int rc = kg_launch_transpose16(in, out, rows, cols, ld_in, ld_out, batch, s_in, s_out, (hipStream_t)stream);

@@ -59,6 +59,41 @@ def test_products_against_fp32(dtype, tile, monkeypatch):
     assert torch.allclose(mm(X, W, out_f32=True, alpha=0.25), 0.25 * mm(X, W, out_f32=True))
 
 
+def test_direct_to_lds_tiles_repeat_bit_for_bit_and_equal_the_register_staged_tile(monkeypatch):
+    """The two tile forms whose loads write LDS directly run several half tiles ahead of their readers with counted waits
+    between raw barriers; a read placed a phase too early, or a refill a phase too soon, shows as a rare wrong tile, not as a
+    crash.  Every form walks K in the same order per accumulator, so the fp32 results must equal the register-staged
+    tile's bit for bit, launch after launch, at sizes with many steps, many tiles per CU, ragged edges, odd step counts and
+    K ranges on grid.y."""
+    g = torch.Generator(device=DEV).manual_seed(11)
+    lib = _lib.lib()
+    for (M, N, K) in ((2048, 4096, 4096), (640, 4352, 1984), (1500, 1024, 8192), (300, 520, 4160), (256, 256, 64), (1100, 2000, 192)):
+        A = torch.randn(M, K, device=DEV, generator=g).to(torch.float16); B = torch.randn(N, K, device=DEV, generator=g).to(torch.float16)
+        Bp = pack_weight(B) if K % 32 == 0 else None
+        monkeypatch.setenv("KG_MM_TILE", "2")
+        want = mm(A, B, out_f32=True)
+        for tile in ("3", "4"):
+            monkeypatch.setenv("KG_MM_TILE", tile)
+            for rep in range(12):
+                assert torch.equal(mm(A, B, out_f32=True), want), (M, N, K, tile, rep)
+                if Bp is not None:
+                    assert torch.equal(mm(A, Bp, out_f32=True, layout=1, N=N), want), (M, N, K, tile, rep, "packed")
+    # K ranges: partial products of whole 64-steps, added in range order, against the one-range product in fp32
+    monkeypatch.delenv("KG_MM_TILE")
+    M, N, K = 640, 4096, 11008
+    A = torch.randn(M, K, device=DEV, generator=g).to(torch.float16); B = torch.randn(N, K, device=DEV, generator=g).to(torch.float16)
+    ref = A.float() @ B.float().T
+    for n in (2, 3, 8):
+        part = torch.full((n, M, N), float("nan"), dtype=torch.float32, device=DEV)
+        _lib.check(lib.kg_matmul_nt_ranges(_lib.DT_F16, A.data_ptr(), B.data_ptr(), part.data_ptr(), M, N, K, K, K, N, 0, n, M * N, st()), "kg_matmul_nt_ranges")
+        assert not bool(torch.isnan(part).any())
+        assert float((part.sum(0) - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-4
+        for rep in range(4):
+            again = torch.empty_like(part)
+            _lib.check(lib.kg_matmul_nt_ranges(_lib.DT_F16, A.data_ptr(), B.data_ptr(), again.data_ptr(), M, N, K, K, K, N, 0, n, M * N, st()), "kg_matmul_nt_ranges")
+            assert torch.equal(again, part)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("tile", [0, 3, 4])
 def test_causal_and_head_strided_products(dtype, tile, monkeypatch):
