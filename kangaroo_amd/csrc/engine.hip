@@ -1511,7 +1511,7 @@ extern "C" int kg_matmul_nt_heads(int dtype, const void* A, const void* B, void*
     a.batch_inner = batch_inner; a.sA2 = sA2; a.sB2 = sB2; a.sC2 = sC2; a.b_inner_div = b_inner_div;
     { const char* t = getenv("KG_MM_TILE"); a.tile = t ? atoi(t) : 0; }      // measurements: 1 forces 128 x 128 tiles, 2 / 3 the two forms of 256 x 256
     const int rc = kg_launch_mm(a, dtype, (hipStream_t)stream);
-    if (rc == -1) return fail(-1, "kg_matmul_nt: bad shape (K and the row / batch strides of A and B must be multiples of 8; a packed B needs K % 32 == 0 and batch 1)");
+    if (rc == -1) return fail(-1, "kg_matmul_nt: bad shape (K and the row / batch strides of A and B must be multiples of 8; a packed B needs K % 32 == 0 and batch 1; one product's A and B each span less than 2 GiB)");
     if (rc) return fail(rc, "kg_matmul_nt launch failed");
     return 0;
 }

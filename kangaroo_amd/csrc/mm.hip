@@ -344,10 +344,11 @@ __global__ void __launch_bounds__(512) kg_mm8_kernel(const KgMmArgs a) {
         const int k0 = (kt0 + u) * MM_BK;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const bool ok = u < KT && k0 + (is_b ? b_k[g] : a_k[g]) < k_end && src[g] != 0xFFFFFFFFu;
-            const unsigned adv = (BMODE == 1 && is_b) ? (unsigned)((k0 >> 5) * 1024) : (unsigned)(k0 * 2);
+            // a step past the last one: the advance alone throws the offset out of range (no branch on the uniform test)
+            const unsigned adv = u < KT ? ((BMODE == 1 && is_b) ? (unsigned)((k0 >> 5) * 1024) : (unsigned)(k0 * 2)) : 0x80000000u;
+            const bool ok = k0 + (is_b ? b_k[g] : a_k[g]) < k_end && src[g] < 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + (8 * g + wave) * 1024), 16,
-                                                     ok ? src[g] + adv : 0xFFFFFFFFu, 0, 0, 0);
+                                                     (ok ? src[g] : 0x7FFFFFFFu) + adv, 0, 0, 0);
         }
     };
 
@@ -495,10 +496,10 @@ __global__ void __launch_bounds__(512) kg_mm8h_kernel(const KgMmArgs a) {
         const int k0 = (kt0 + u) * MM_BK;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const bool ok = u < KT && k0 + (is_b ? b_k[g] : a_k[g]) < k_end && src[g] != 0xFFFFFFFFu;
-            const unsigned adv = (BMODE == 1 && is_b) ? (unsigned)((k0 >> 5) * 1024) : (unsigned)(k0 * 2);
+            const unsigned adv = u < KT ? ((BMODE == 1 && is_b) ? (unsigned)((k0 >> 5) * 1024) : (unsigned)(k0 * 2)) : 0x80000000u;
+            const bool ok = k0 + (is_b ? b_k[g] : a_k[g]) < k_end && src[g] < 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + (8 * g + wave) * 1024), 16,
-                                                     ok ? src[g] + adv : 0xFFFFFFFFu, 0, 0, 0);
+                                                     (ok ? src[g] : 0x7FFFFFFFu) + adv, 0, 0, 0);
         }
     };
 
@@ -630,6 +631,12 @@ int kg_launch_mm(const KgMmArgs& a, int dtype, hipStream_t st) {
     if (a.causal < 0 || a.causal > 4 || (a.causal == 4 && a.b_packed != 2)) return -1;
     if (a.batch_inner < 1 || a.batch % a.batch_inner || a.b_inner_div < 1 || (a.sA2 & 7) || (a.sB2 & 7)) return -1;
     if (a.tile < 0 || a.tile > 4) return -1;
+    {   // one product's operands are addressed with 32-bit byte offsets
+        const unsigned long long ea = ((unsigned long long)(a.M - 1) * a.lda + a.K) * 2;
+        const unsigned long long eb = a.b_packed == 1 ? (unsigned long long)((a.N + 15) / 16) * (a.K / 32) * 1024
+                                    : (a.b_packed == 2 ? ((unsigned long long)(a.K - 1) * a.ldb + a.N) * 2 : ((unsigned long long)(a.N - 1) * a.ldb + a.K) * 2);
+        if (ea >= 0x7fffffffull || eb >= 0x7fffffffull) return -1;
+    }
     if (a.ksplit < 0 || a.ksplit > 64 || (a.ksplit > 1 && (!a.out_f32 || a.epi || a.causal || a.batch != 1 || a.b_packed == 2 || a.tile == 1 || a.tile == 2 || a.sCk < (long long)a.M * a.ldc))) return -1;
     if (a.epi < 0 || a.epi > 2 || (a.epi && (a.out_f32 || a.batch != 1)) || (a.epi == MM_EPI_RESID && !a.resid) || (a.epi == MM_EPI_SILU_MUL && (a.N & 1))) return -1;
     if (dtype == KG_F16) { if (a.b_packed == 1) mm_launch<KG_F16, 1>(a, st); else if (a.b_packed == 2) mm_launch<KG_F16, 2>(a, st); else mm_launch<KG_F16, 0>(a, st); }
