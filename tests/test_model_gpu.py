@@ -17,7 +17,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from kangaroo_amd.config import get_shape
+from kangaroo_amd.config import LlamaShape, get_shape
 from kangaroo_amd.inference import kangaroo_forward, kangaroo_forward_stepwise, vanilla_forward
 from kangaroo_amd.kangaroo_model import KangarooModel
 from kangaroo_amd.weights import Recipe, synth_state_dicts
@@ -525,8 +525,8 @@ def test_persistent_pass_is_bit_identical_to_kernel_by_kernel(shape_name, dtype)
 
 
 @pytest.mark.parametrize("shape_name,dtype", [("small", torch.float16), ("tinyllama-1.1b", torch.float16), ("vicuna-7b", torch.float16),
-                                              ("vicuna-13b", torch.float16), ("llama-33b", torch.bfloat16)],
-                         ids=["small", "tinyllama-1.1b", "vicuna-7b", "vicuna-13b", "llama-33b-bf16"])
+                                              ("vicuna-13b", torch.float16), ("llama-33b", torch.bfloat16), ("gqa-hd128", torch.float16)],
+                         ids=["small", "tinyllama-1.1b", "vicuna-7b", "vicuna-13b", "llama-33b-bf16", "gqa-hd128"])
 def test_gemm_prefill_matches_chunked_prefill(shape_name, dtype):
     """Prompts longer than 16 tokens are prefilled in one 128-row GEMM pass, from 129 tokens on layer by layer over the
     whole prompt (one matrix product per projection, csrc/mm.hip; the d-column projections of a short prompt in K
@@ -534,7 +534,8 @@ def test_gemm_prefill_matches_chunked_prefill(shape_name, dtype):
     in 16-row passes of the decode kernels.  Same math, different K summation order: caches and the first token's
     hidden state agree to 16-bit rounding noise.  The real layer shapes (d 4096 / 5120 / 6656, 32 / 40 / 52 heads) run
     with three layers."""
-    shape = get_shape(shape_name)
+    # grouped query heads at head_dim 128 (8 query heads on 2 key / value heads): no configuration of the reference has both
+    shape = LlamaShape(1024, 3, 8, 2, 2816, 4000) if shape_name == "gqa-hd128" else get_shape(shape_name)
     if shape_name == "tinyllama-1.1b":
         shape = type(shape)(**{**shape.to_dict(), "num_hidden_layers": 4})
     if shape_name in ("vicuna-7b", "vicuna-13b", "llama-33b"):
@@ -549,7 +550,7 @@ def test_gemm_prefill_matches_chunked_prefill(shape_name, dtype):
     # of it) apart, and a value next to a rounding boundary two; fp16 has 8 times finer spacing
     tol = 1e-2 if dtype == torch.float16 else 2 * 2.0 ** -7
     worst = 0.0
-    for plen in (17, 64, 65, 129, 200, 333):
+    for plen in (17, 64, 65, 129, 200, 257, 333, 511):          # 257: one row past two 128-row tiles; 511: the last row block short by one
         ids = torch.randint(3, shape.vocab_size, (1, plen), generator=g).cuda()
         caches = {}
         for mode in (2, 1):
