@@ -269,7 +269,7 @@ def test_against_live_oracle(shape_name, L, recipe, seed):
     model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, L)
     om = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), base, adapter, L)
     g = torch.Generator().manual_seed(seed)
-    for plen in (9, 40):
+    for plen in (9, 40, 150):                       # 150: the prompt goes through the layers as a whole (one product per projection)
         ids = torch.randint(3, shape.vocab_size, (1, plen), generator=g)
         tr = ko.Trace()
         ref = ko.kangaroo_forward(ids, om, 2, 48, EARLY_STOP_LAYER=L, trace=tr, keep_logits=True)
@@ -639,7 +639,7 @@ def test_real_layer_shapes_against_live_oracle(name, L, n_layers, dtype, tol, re
     om = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), {k: v.cpu() for k, v in base.items()}, {k: v.cpu() for k, v in adapter.items()}, L)
     del base, adapter
     g = torch.Generator().manual_seed(61)
-    for plen in (11, 37):
+    for plen in (11, 37, 160):                      # 160: the whole-prompt pass (matrix products of csrc/mm.hip, K ranges, shared-key attention)
         ids = torch.randint(3, shape.vocab_size, (1, plen), generator=g)
         tr = ko.Trace()
         ref = ko.kangaroo_forward(ids, om, 2, 40, EARLY_STOP_LAYER=L, trace=tr, keep_logits=True)
