@@ -540,8 +540,9 @@ __global__ void __launch_bounds__(256, 2) kg_attn_rows128_kernel(const unsigned 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         // q.k^T stored, then divided by sqrt(hd) and stored.  The quotient by a constant: one product with the
-                        // rounded reciprocal and one correction step give the correctly rounded fp32 quotient (Markstein), the
-                        // same bits as the division.
+                        // rounded reciprocal and one correction step give the correctly rounded fp32 quotient (Markstein): for
+                        // every finite 16-bit x and sqrt(32 / 64 / 128) the same bits as the division, but for the sign of a
+                        // zero quotient and x below 2^-126 (checked exhaustively on the host).
                         const float x = kg_round<DT>(d[e]);
                         const float q0 = x * rcp_scale;
                         sc[qt][4 * kt + e] = kg_round<DT>(__builtin_fmaf(__builtin_fmaf(-q0, inv_scale, x), rcp_scale, q0));
