@@ -243,6 +243,15 @@ int kg_forward_layers(kg_session* s, int layer_begin, int layer_end, const void*
                       void* h_out, void* stream);
 /* model.norm (earlyexit.py:69) */
 int kg_final_norm(kg_session* s, const void* x, int n_rows, void* out, void* stream);
+/* The prefill call of the loop (evaluation/inference_kangaroo.py:30-35: `model.base_model(input_ids, position_ids,
+ * output_hidden_states=True)`) as ONE pass over the whole prompt, every projection a single matrix product: tokens [0, n_tokens)
+ * (kg_set_tokens) through all layers with cache append; early_out [n_tokens][d] = hidden_states[exit_layer], final_out
+ * [n_tokens][d] = hidden_states[-1] (after the final norm), logits_out [n_tokens][vocab] (16 bit; NULL: not computed).
+ * Returns -3 when the session cannot run it (see kg_last_error); the caller then makes 16-row kg_forward_layers calls. */
+int kg_prefill_rows(kg_session* s, int n_tokens, void* early_out, void* final_out, void* logits_out, void* stream);
+/* AdapterModel.forward_early_stop (kangaroo/adapter.py:378-460) on a whole prompt's rows at positions 0 .. n_rows - 1 (the
+ * adapter prefill of evaluation/inference_kangaroo.py:36-38), as one pass. */
+int kg_adapter_forward_rows(kg_session* s, const void* x_in, int n_rows, void* h_out, void* stream);
 /* AdapterModel.forward_early_stop (kangaroo/adapter.py:378-460) on n_rows rows at pos0.. */
 int kg_adapter_forward(kg_session* s, const void* x_in, int pos0, int n_rows, void* h_out, void* stream);
 /* head_model (kangaroo/kangaroo_model.py:34-44) on already-normalised rows; n_rows == -1: one row in a

@@ -81,6 +81,8 @@ SYMBOLS = {
     "kg_set_tokens": (_I, [_VP, C.POINTER(C.c_int32), _I, _I, _VP]),
     "kg_forward_layers": (_I, [_VP, _I, _I, _VP, _I, _I, _VP, _VP]),
     "kg_final_norm": (_I, [_VP, _VP, _I, _VP, _VP]),
+    "kg_prefill_rows": (_I, [_VP, _I, _VP, _VP, _VP, _VP]),
+    "kg_adapter_forward_rows": (_I, [_VP, _VP, _I, _VP, _VP]),
     "kg_adapter_forward": (_I, [_VP, _VP, _I, _I, _VP, _VP]),
     "kg_head_logits": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "kg_tp_xbuf_bytes": (_SZ, [_I, _I]),

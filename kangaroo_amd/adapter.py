@@ -49,11 +49,15 @@ class AdapterModel:
             raise ValueError("sequence exceeds the cache")
         _check_positions(position_ids, past, q_len)
         x = inputs_embeds[0]
-        out = torch.empty((q_len, d), dtype=e.dtype, device=e.device)
-        C = e.get_tuning("prefill_rows")
-        for c0 in range(0, q_len, C):
-            n = min(C, q_len - c0)
-            out[c0:c0 + n] = e.adapter_forward(x[c0:c0 + n], past + c0, n)
+        whole = e.whole_prompt_rows()
+        if whole and past == 0 and q_len >= whole:
+            out = e.adapter_forward_rows(x, q_len)                # the adapter's prompt pass as a whole (inference_kangaroo.py:36-38)
+        else:
+            out = torch.empty((q_len, d), dtype=e.dtype, device=e.device)
+            C = e.get_tuning("prefill_rows")
+            for c0 in range(0, q_len, C):
+                n = min(C, q_len - c0)
+                out[c0:c0 + n] = e.adapter_forward(x[c0:c0 + n], past + c0, n)
         hidden = out.unsqueeze(0)
         if use_cache:
             return hidden, self._views(past + q_len)

@@ -1122,6 +1122,49 @@ static int prefill_rows_pass(kg_session* s, int T0, bool with_adapter, hipStream
     return 0;
 }
 
+// The whole-prompt pass behind the stepwise interface (the prefill call of evaluation/inference_kangaroo.py:30-35 made through
+// the mirror classes): tokens [0, n) through all layers, the exit layer's input rows and the post-norm last hidden rows to the
+// caller, logits of all rows (one matrix product with the head) when asked for.
+extern "C" int kg_prefill_rows(kg_session* s, int n_tokens, void* early_out, void* final_out, void* logits_out, void* stream) {
+    g_err.clear();
+    hipStream_t st = (hipStream_t)stream;
+    if (!s || !early_out || !final_out) return fail(-1, "null argument");
+    const kg_shape& sh = s->sh;
+    const int d = sh.hidden_size, L = sh.exit_layer, N = sh.num_layers, dt = sh.dtype;
+    if (n_tokens < 1 || n_tokens > s->buf.t_max) return fail(-1, "token count exceeds the cache");
+    if (s->rows_prefill_min <= 0 || s->tp.size != 0 || L >= N) return fail(-3, "the whole-prompt pass is not available for this session (head_dim < 32, a cache length that is no multiple of 32, sizes that are no multiples of 8, or tensor-parallel layers)");
+    KG_TRY(kg_launch_rows_embed(s->tokens, 0, n_tokens, s->w.embed, d, s->pm_h, st));
+    const void* cur = s->pm_h;
+    for (int l = 0; l < N; ++l) {
+        void* dst = (l == L - 1) ? (void*)s->hs_early : (void*)s->pm_h;
+        KG_TRY(run_layer_rows(s, s->layers[l], layer_k(s, l), layer_v(s, l), n_tokens, cur, dst, st));
+        cur = dst;
+    }
+    KG_CHECK_HIP(hipMemcpyAsync(early_out, s->hs_early, (size_t)n_tokens * d * s->elt, hipMemcpyDeviceToDevice, st));
+    KG_TRY(kg_launch_rows_rmsnorm(cur, d, s->w.final_norm, sh.rms_eps, d, final_out, d, n_tokens, dt, st));
+    if (logits_out) {
+        KgMmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.A = final_out; a.B = s->w.lm_head; a.C = logits_out; a.M = n_tokens; a.N = sh.vocab_size; a.K = d; a.lda = d; a.ldc = sh.vocab_size;
+        a.batch = 1; a.batch_inner = 1; a.b_inner_div = 1; a.b_packed = 1; a.alpha = 1.0f;
+        if (kg_launch_mm(a, dt, st)) return fail(-2, "kg_prefill_rows: the head product failed to launch");
+    }
+    return 0;
+}
+
+// The adapter over a whole prompt (positions 0 .. n_rows - 1, evaluation/inference_kangaroo.py:36-38): one matrix product per
+// projection, the adapter's norm on every row.
+extern "C" int kg_adapter_forward_rows(kg_session* s, const void* x_in, int n_rows, void* h_out, void* stream) {
+    g_err.clear();
+    hipStream_t st = (hipStream_t)stream;
+    if (!s || !x_in || !h_out) return fail(-1, "null argument");
+    const kg_shape& sh = s->sh;
+    if (n_rows < 1 || n_rows > s->buf.t_max) return fail(-1, "row count exceeds the cache");
+    if (s->rows_prefill_min <= 0) return fail(-3, "the whole-prompt pass is not available for this session");
+    KG_TRY(run_layer_rows(s, s->w.adapter, s->buf.ak_cache, s->buf.av_cache, n_rows, x_in, s->pm_h, st));
+    return kg_launch_rows_rmsnorm(s->pm_h, sh.hidden_size, s->w.adapter_norm, sh.rms_eps, sh.hidden_size, h_out, sh.hidden_size, n_rows, sh.dtype, st);
+}
+
 static int prefill(kg_session* s, int T0, bool with_adapter, hipStream_t st) {
     const kg_shape& sh = s->sh;
     const int d = sh.hidden_size, L = sh.exit_layer, N = sh.num_layers;

@@ -92,6 +92,13 @@ class EarlyExitLlamaForCausalLM:
         _check_positions(position_ids, 0, T)
         e.set_tokens(ids, 0)
         L, N, d = self.early_exit_layer, e.shape.num_hidden_layers, e.shape.hidden_size
+        whole = e.whole_prompt_rows()
+        if whole and T >= whole and L == e.exit_layer:
+            # the prompt through the layers as a whole, one matrix product per projection (what the fused loop's prefill runs)
+            early, final, lg = e.prefill_rows(T, logits_rows == "all")
+            lg = (lg if lg is not None else e.head_logits(final[T - 1:T])).unsqueeze(0)
+            pkv = tuple(self._views(l, T) for l in range(N))
+            return BaseModelOutput(lg, _HiddenStates(N, {L: early.unsqueeze(0), N: final.unsqueeze(0)}), pkv)
         C = self._chunk_rows()
         early = torch.empty((T, d), dtype=e.dtype, device=e.device)
         final = torch.empty((T, d), dtype=e.dtype, device=e.device)

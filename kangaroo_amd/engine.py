@@ -268,6 +268,25 @@ class KangarooEngine:
                    "kg_forward_layers")
         return out
 
+    def whole_prompt_rows(self) -> int:
+        """Prompts of at least this many tokens go through the layers as a whole (0: this session cannot)."""
+        return 0 if self.tp_plan is not None else self.get_tuning("rows_prefill_min")
+
+    def prefill_rows(self, n_tokens: int, all_logits: bool):
+        """kg_prefill_rows: (hidden_states[exit_layer], hidden_states[-1], logits of every row or None) for tokens [0, n)."""
+        d = self.shape.hidden_size
+        early = torch.empty((n_tokens, d), dtype=self.dtype, device=self.device)
+        final = torch.empty((n_tokens, d), dtype=self.dtype, device=self.device)
+        logits = torch.empty((n_tokens, self.shape.vocab_size), dtype=self.dtype, device=self.device) if all_logits else None
+        _lib.check(self.lib.kg_prefill_rows(self._handle, n_tokens, _ptr(early), _ptr(final), _ptr(logits), _stream()), "kg_prefill_rows")
+        return early, final, logits
+
+    def adapter_forward_rows(self, x_in: torch.Tensor, n_rows: int) -> torch.Tensor:
+        x_in = x_in.reshape(n_rows, self.shape.hidden_size).to(self.dtype).contiguous()
+        out = torch.empty_like(x_in)
+        _lib.check(self.lib.kg_adapter_forward_rows(self._handle, _ptr(x_in), n_rows, _ptr(out), _stream()), "kg_adapter_forward_rows")
+        return out
+
     def final_norm(self, x: torch.Tensor) -> torch.Tensor:
         n = x.shape[0]
         x = x.contiguous()

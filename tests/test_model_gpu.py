@@ -618,6 +618,62 @@ def test_reference_loop_drives_the_mirror_classes(path):
         model.base_model(torch.tensor([[3, shape.vocab_size]]).cuda())          # token id beyond the embedding table
 
 
+@pytest.mark.parametrize("shape_name", ["small", "tinyllama-1.1b"])
+def test_mirror_classes_prefill_a_long_prompt_as_a_whole(shape_name):
+    """`model.base_model(input_ids, output_hidden_states=True)` and the adapter's prompt pass of the reference's loop
+    (evaluation/inference_kangaroo.py:30-38) on a 200-token prompt: one pass over the whole prompt (kg_prefill_rows,
+    kg_adapter_forward_rows) instead of thirteen 16-row calls.  Logits of ALL rows and both hidden-state tensors against the
+    fp32 oracle, the caches against the ones the fused loop's prefill leaves (the same pass: equal bits), and the reference's
+    loop driven over the classes against the oracle's loop."""
+    shape = get_shape(shape_name)
+    if shape_name == "tinyllama-1.1b":
+        shape = type(shape)(**{**shape.to_dict(), "num_hidden_layers": 4})
+    L = 2
+    base, adapter = synth_state_dicts(shape, L, seed=91, dtype=torch.float16, recipe=Recipe.agreeable(0.3, 8.0))
+    model = KangarooModel.from_state_dicts(shape, base, adapter, torch.float16, L)
+    om = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), base, adapter, L)
+    eng = model.engine
+    assert eng.whole_prompt_rows() == 129
+    g = torch.Generator().manual_seed(91)
+    ids = torch.randint(3, shape.vocab_size, (1, 200), generator=g)
+    dev = model.base_model(ids.cuda(), output_hidden_states=True)
+    ref = om.base_model(ids)
+    assert dev.logits.shape == (1, 200, shape.vocab_size)
+    for name, a, b in (("logits", dev.logits, ref.logits), ("hidden_states[L]", dev.hidden_states[L], ref.hidden_states[L]),
+                       ("hidden_states[-1]", dev.hidden_states[-1], ref.hidden_states[-1])):
+        err = float((a.float().cpu() - b).abs().max()) / float(b.abs().max())
+        print(f"[whole-prompt prefill {shape_name}] {name}: {err:.2e} of max-abs")
+        assert err <= LOGIT_TOL, name
+    assert dev.past_key_values[0][0].shape[2] == 200
+    k_step, v_step = eng.k_cache.clone(), eng.v_cache.clone()
+    # the adapter's prompt pass (rows 0 .. 198 of hidden_states[L]) against the oracle's adapter and against 16-row passes
+    x = dev.hidden_states[L][:, :-1]
+    a_dev, _ = model.adapter_model.forward_early_stop(inputs_embeds=x, position_ids=torch.arange(199, device="cuda").view(1, -1), use_cache=True)
+    ak_rows = eng.ak_cache.clone()
+    a_ref, _ = om.adapter_model.forward_early_stop(inputs_embeds=x.float().cpu(), position_ids=torch.arange(199).view(1, -1), use_cache=True)
+    assert float((a_dev.float().cpu() - a_ref).abs().max()) <= LOGIT_TOL * float(a_ref.abs().max())
+    eng.set_tuning(rows_prefill_min=1)                   # off: 16-row passes of the decode kernels
+    a_16, _ = model.adapter_model.forward_early_stop(inputs_embeds=x, position_ids=torch.arange(199, device="cuda").view(1, -1), use_cache=True)
+    eng.set_tuning(rows_prefill_min=129)
+    assert float((a_dev.float() - a_16.float()).abs().max()) <= LOGIT_TOL * float(a_16.float().abs().max())
+    assert float((ak_rows.float() - eng.ak_cache.float()).abs().max()) <= LOGIT_TOL * float(ak_rows.float().abs().max())
+    # the fused loop's prefill is the same pass over the same rows: the same cache bits
+    eng.generate(ids[0], 1, mode="kangaroo")
+    assert torch.equal(eng.k_cache[..., :200, :], k_step[..., :200, :])
+    if eng.get_tuning("v_transposed"):
+        assert torch.equal(eng.v_cache[..., :200], v_step[..., :200])
+    else:
+        assert torch.equal(eng.v_cache[..., :200, :], v_step[..., :200, :])
+    # the reference's loop over the classes
+    tr = ko.Trace()
+    rf = ko.kangaroo_forward(ids, om, 2, 40, EARLY_STOP_LAYER=L, trace=tr, keep_logits=True)
+    trd = ko.Trace()
+    out = ko.kangaroo_forward(ids.cuda(), model, 2, 40, EARLY_STOP_LAYER=L, trace=trd)
+    check_against_reference(f"refloop-long:{shape_name}", "plen200", (out[0][0], out[3], trd.draft_lengths, out[1], out[2]),
+                            (rf[0][0], rf[3], tr.draft_lengths, rf[1], rf[2]), 200, tr.p_max, tr.draft_logits, torch.cat(tr.verify_logits, 0), 0.6,
+                            lambda: om)
+
+
 def _cut(shape, n_layers):
     return type(shape)(**{**shape.to_dict(), "num_hidden_layers": n_layers})
 
