@@ -71,6 +71,12 @@ def cpu_baseline(shape, L, base_sd_gpu, adapter_sd_gpu, steps, thr, model, n_pro
     adapter = {k: v.to("cpu") for k, v in adapter_sd_gpu.items()}
     om = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), base, adapter, L)
     del base, adapter
+    # the same base model (same fp32 copies of the weights) with every stored tensor rounded to the device's type: what the
+    # reference's own arithmetic in that type would give; only used to size the logits-row check of a traced difference
+    import copy
+    rounding = copy.copy(om.base_model)
+    rounding.round_to = torch.bfloat16 if str(model.engine.dtype).endswith("bfloat16") else torch.float16
+    rounding.past_key_values = None
     setup = time.time() - t0
     tot_new, tot_dt, accepts, diffs, same_tokens, cmp_tokens = 0, 0.0, [], [], 0, 0
     for i in range(n_prompts):
@@ -87,7 +93,8 @@ def cpu_baseline(shape, L, base_sd_gpu, adapter_sd_gpu, steps, thr, model, n_pro
                                                          SPECULATIVE_DECODING_STEPS=steps, threshold=thr, return_stats=True)
         rec = parity.first_difference(out[0], accept, st.draft_lengths, ref[0][0], ref[3], tr.draft_lengths, prompt_len, om,
                                       tr.p_max, tr.draft_logits, thr,
-                                      dev_logits_row=lambda pre: model.base_model(torch.tensor([pre]).cuda(), logits_rows="last").logits[0, -1])
+                                      dev_logits_row=lambda pre: model.base_model(torch.tensor([pre]).cuda(), logits_rows="last").logits[0, -1],
+                                      rounding_model=rounding)
         rec["prompt_seed"] = 7 + i
         diffs.append(rec)
         n = min(len(out[0]), len(ref[0][0]))

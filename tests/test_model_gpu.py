@@ -674,6 +674,35 @@ def test_mirror_classes_prefill_a_long_prompt_as_a_whole(shape_name):
                             lambda: om)
 
 
+def test_full_depth_error_against_fp32_and_against_the_reference_arithmetic_in_16_bit():
+    """The 1e-2 bar against the fp32 oracle is checked at the real layer shapes with the layer count cut.  At the real DEPTH
+    (32 layers, narrower so that the CPU oracle takes seconds) fp16 still meets it; bf16 cannot, whoever computes it: the
+    oracle run with every stored tensor rounded to bf16 -- the reference's own arithmetic in that type, op boundary by op
+    boundary -- sits 1.5 .. 1.9e-2 of max-abs from its fp32 self.  The device is held to that: no further from fp32 than
+    1.5 x the reference arithmetic's own distance (measured on MI355X: see the printed lines)."""
+    shape = LlamaShape(1024, 32, 8, 8, 2816, 32000)
+    L = 2
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(3, shape.vocab_size, (1, 32), generator=g)
+    for dtype in (torch.float16, torch.bfloat16):
+        base, adapter = synth_state_dicts(shape, L, seed=0, dtype=dtype, recipe=Recipe.agreeable(0.08, 10.0))
+        model = KangarooModel.from_state_dicts(shape, base, adapter, dtype, L)
+        ref = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), base, adapter, L).base_model(ids).logits[0]
+        rnd = ko.OracleKangarooModel(ko.Shape(**shape.to_dict()), base, adapter, L, round_to=dtype).base_model(ids).logits[0]
+        dev = model.base_model(ids.cuda()).logits[0].float().cpu()
+        scale = ref.abs().amax(-1)
+        e_dev = float(((dev - ref).abs().amax(-1) / scale).max())
+        e_ref = float(((rnd - ref).abs().amax(-1) / scale).max())
+        e_dr = float(((dev - rnd).abs().amax(-1) / scale).max())
+        print(f"[depth 32, {str(dtype).split('.')[-1]}] logits, max over 32 rows, of the row's max-abs: device vs fp32 oracle {e_dev:.2e}; "
+              f"oracle with {str(dtype).split('.')[-1]} op boundaries vs fp32 oracle {e_ref:.2e}; device vs that oracle {e_dr:.2e}")
+        if dtype == torch.float16:
+            assert e_dev <= LOGIT_TOL
+        assert e_dev <= 1.5 * e_ref
+        del model
+        torch.cuda.empty_cache()
+
+
 def _cut(shape, n_layers):
     return type(shape)(**{**shape.to_dict(), "num_hidden_layers": n_layers})
 
