@@ -582,8 +582,8 @@ __global__ void __launch_bounds__(256, 2) kg_attn_rows128_kernel(const unsigned 
                 mrun[qt] = mnew;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    pf[qt][ks].x = T::from_f(p[8 * ks + 0]) | ((unsigned)T::from_f(p[8 * ks + 1]) << 16); pf[qt][ks].y = T::from_f(p[8 * ks + 2]) | ((unsigned)T::from_f(p[8 * ks + 3]) << 16);
-                    pf[qt][ks].z = T::from_f(p[8 * ks + 4]) | ((unsigned)T::from_f(p[8 * ks + 5]) << 16); pf[qt][ks].w = T::from_f(p[8 * ks + 6]) | ((unsigned)T::from_f(p[8 * ks + 7]) << 16);
+                    pf[qt][ks].x = kg_pack2<DT>(p[8 * ks + 0], p[8 * ks + 1]); pf[qt][ks].y = kg_pack2<DT>(p[8 * ks + 2], p[8 * ks + 3]);
+                    pf[qt][ks].z = kg_pack2<DT>(p[8 * ks + 4], p[8 * ks + 5]); pf[qt][ks].w = kg_pack2<DT>(p[8 * ks + 6], p[8 * ks + 7]);
                 }
 #pragma unroll
                 for (int b = 0; b < 8; ++b) O[qt][b] = O[qt][b] * scale;

@@ -111,6 +111,20 @@ template <> struct KgT<KG_BF16> {
     }
 };
 
+// two fp32 values rounded (to nearest even) to the storage type and packed, low half first: one v_cvt_pk_f16_f32 /
+// v_cvt_pk_bf16_f32 on gfx950, the same bits as two from_f calls
+template <int DT> __device__ __forceinline__ unsigned kg_pack2(float a, float b);
+template <> __device__ __forceinline__ unsigned kg_pack2<KG_F16>(float a, float b) {
+    typedef _Float16 kg_h2v __attribute__((ext_vector_type(2)));
+    typedef float kg_f2v __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(kg_f2v{a, b}, kg_h2v));
+}
+template <> __device__ __forceinline__ unsigned kg_pack2<KG_BF16>(float a, float b) {
+    typedef __bf16 kg_b2v __attribute__((ext_vector_type(2)));
+    typedef float kg_f2v __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(kg_f2v{a, b}, kg_b2v));
+}
+
 // round an fp32 value to the storage type and back (the reference's per-op store)
 template <int DT> __device__ __forceinline__ float kg_round(float f) { return KgT<DT>::to_f(KgT<DT>::from_f(f)); }
 
